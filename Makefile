@@ -1,0 +1,39 @@
+# Builds the three shared libraries in-tree:
+#   raytracer_amd/lib/librt_hip.so   HIP backend (C ABI of include/rt_hip.h), gfx950 only
+#   raytracer_amd/lib/librt_host.so  C++ host layer (RayScene/RayEngine/...), links the backend
+#   oracle/liboracle.so              CPU checker (test infrastructure)
+HIPCC ?= /opt/rocm/bin/hipcc
+CXX ?= g++
+ARCH ?= gfx950
+
+LIBDIR := raytracer_amd/lib
+CSRC := raytracer_amd/csrc
+HOST := raytracer_amd/host
+
+# -ffp-contract=off + correctly rounded divide/sqrt: required by rt_math.h's bit-exact contract.
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt \
+            -fno-fast-math -Wall -Wno-unused-function -Wno-unused-result -Wno-unused-value -Iinclude -I$(CSRC)
+HOSTFLAGS := -std=c++17 -O2 -fPIC -ffp-contract=off -Wall -Wextra -Wno-unused-parameter -Iinclude -I$(HOST)
+
+HOST_SRCS := $(HOST)/AABB.cpp $(HOST)/BVHTree.cpp $(HOST)/MeshData.cpp $(HOST)/TraceableObject.cpp $(HOST)/RayScene.cpp \
+             $(HOST)/RaySceneBuilder.cpp $(HOST)/RayTracer.cpp $(HOST)/RayEngine.cpp $(HOST)/ProceduralMesh.cpp \
+             $(HOST)/host_capi.cpp $(HOST)/gpu/HipStorage.cpp
+HOST_HDRS := $(wildcard $(HOST)/*.h $(HOST)/gpu/*.h $(HOST)/glm/*.hpp $(HOST)/glm/gtc/*.hpp) include/rt_hip.h include/rt_host.h
+
+all: $(LIBDIR)/librt_hip.so $(LIBDIR)/librt_host.so oracle/liboracle.so
+
+$(LIBDIR)/librt_hip.so: $(CSRC)/rt_hip.hip $(CSRC)/rt_device.h $(CSRC)/rt_bsdf.h $(CSRC)/rt_math.h include/rt_hip.h
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -shared $(CSRC)/rt_hip.hip -o $@
+
+$(LIBDIR)/librt_host.so: $(HOST_SRCS) $(HOST_HDRS) $(LIBDIR)/librt_hip.so
+	@mkdir -p $(LIBDIR)
+	$(CXX) $(HOSTFLAGS) -shared $(HOST_SRCS) -o $@ -L$(LIBDIR) -lrt_hip -Wl,-rpath,'$$ORIGIN'
+
+oracle/liboracle.so: oracle/oracle.cpp oracle/oracle_spectral.inc $(CSRC)/rt_math.h
+	$(MAKE) -C oracle liboracle.so
+
+clean:
+	rm -f $(LIBDIR)/*.so oracle/liboracle.so
+
+.PHONY: all clean

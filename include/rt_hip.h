@@ -1,0 +1,135 @@
+/* rt_hip.h — C ABI of the MI355X path-tracing backend (librt_hip.so).
+ *
+ * This is the boundary a maintainer of the reference renderer binds instead of
+ * its OpenGL path: flat float streams in, accumulated RGBA32F frames out.
+ * Plain pointers and sizes only; every call returns 0 (RT_OK) or a negative
+ * rt_status; no exceptions cross the boundary.  A context is owned by one
+ * caller thread at a time and uses one HIP stream on one device.
+ *
+ * Each entry point names the reference interface it replaces
+ * (paths relative to the reference tree).
+ */
+#ifndef RT_HIP_H
+#define RT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rt_ctx rt_ctx;
+
+typedef enum rt_status {
+    RT_OK = 0,
+    RT_ERR_INVALID = -1,   /* bad argument (null pointer, size mismatch, bad slot) */
+    RT_ERR_STATE = -2,     /* call out of order (render before commit/resize/set_frame) */
+    RT_ERR_HIP = -3,       /* a HIP runtime call failed; rt_last_hip_error() has the text */
+    RT_ERR_NO_DEVICE = -4, /* no usable GPU */
+    RT_ERR_SCENE = -5,     /* stream contents inconsistent (offsets out of range, depth > stack) */
+    RT_ERR_NOMEM = -6
+} rt_status;
+
+/* Stream slots: the texture-unit numbers of src/RayScene.cpp:30-52. */
+enum {
+    RT_SLOT_OBJECTS = 1,    /* objectsBuffer          src/RayScene.cpp:32 */
+    RT_SLOT_MATERIALS = 2,  /* materialsBuffer        src/RayScene.cpp:36 */
+    RT_SLOT_MODEL_INFO = 3, /* modelInfoObjectsBuffer src/RayScene.cpp:40 */
+    RT_SLOT_MODELS = 4,     /* modelObjectsBuffer     src/RayScene.cpp:44 */
+    RT_SLOT_TEXTURES = 5    /* texturesBuffer         src/RayScene.cpp:48 */
+};
+
+/* Integrator selector: RayTracer::Type, src/RayTracer.h:17-20. */
+enum { RT_TYPE_RGB = 0, RT_TYPE_SPECTRAL = 1 };
+
+/* The `camera.*` uniform block of src/RayTracer.cpp:1441-1448. */
+typedef struct rt_camera {
+    float fov;           /* degrees */
+    float resolution[2]; /* width, height (as floats, like the vec2 uniform) */
+    float position[3];
+    float forward[3];
+    float right[3];
+    float up[3];
+    int32_t bounces;     /* loop runs i = 0..bounces inclusive */
+    int32_t rayPerPixel; /* ssq = int(sqrt(rayPerPixel)); ssq*ssq samples per frame */
+} rt_camera;
+
+/* Work counters of the last rt_render/rt_trace_primary calls since rt_reset_stats. */
+typedef struct rt_stats {
+    uint64_t rays;          /* hit() calls: path segments + NEE shadow rays */
+    uint64_t camera_samples;/* camera samples started */
+    uint64_t node_visits;   /* inner BVH nodes opened (only if counters enabled) */
+    uint64_t tri_tests;     /* ray/triangle tests (only if counters enabled) */
+    uint64_t shaded_hits;   /* hits whose material was resolved */
+    double trace_ms;        /* device time in the traversal kernel (HIP events) */
+    double total_ms;        /* device time of rt_render as a whole */
+    uint64_t trace_launches;
+} rt_stats;
+
+/* Creates a context on HIP device `device`.  Replaces the GL context +
+ * gl::TextureBuffer objects owned by gpu::TBOStorage (src/gpu/TBOStorage.cpp:5-7). */
+int rt_create(rt_ctx **out, int device);
+void rt_destroy(rt_ctx *ctx);
+
+/* gpu::Storage::upload (src/gpu/Storage.h:7; glBufferData in
+ * src/glUtilities/TextureBuffer.cpp:23-38): copies `bytes` of 32-bit words;
+ * the caller may free `data` on return.  bytes may be 0. */
+int rt_upload(rt_ctx *ctx, int slot, const void *data, size_t bytes);
+
+/* RayScene::bindShader + the scene uniforms (src/RayScene.cpp:30-52,
+ * src/RayTracer.cpp:1436-1437): fixes the counts and re-packs the uploaded
+ * streams into the traversal layout (64-byte inner nodes, 48-byte triangles). */
+int rt_commit_scene(rt_ctx *ctx, int objectCount, int modelsCount, int lightSourcesCount);
+
+/* RayTracer::initialize / changeResolution frame textures
+ * (src/RayTracer.cpp:1415-1424, 1454-1465).  Zeroes the accumulation buffer. */
+int rt_resize(rt_ctx *ctx, int width, int height);
+
+/* Per-frame uniforms (src/RayTracer.cpp:1438-1448).  `type` = RT_TYPE_*. */
+int rt_set_frame(rt_ctx *ctx, const rt_camera *cam, const float sky_linear[3], int type);
+
+/* RayTracer::renderToTexture + the full-screen draw (src/RayTracer.cpp:1428-1452,
+ * src/RayEngine.cpp:28-42) for frameCount = first_frame .. first_frame+n_frames-1
+ * in steps of frame_stride (sample-split sharding uses stride = number of GPUs).
+ * Adds each frame's colour into the sum buffer.  Asynchronous on the context's stream. */
+int rt_render(rt_ctx *ctx, uint32_t first_frame, uint32_t n_frames, uint32_t frame_stride);
+
+/* RayTracer::reset (src/RayTracer.cpp:1467-1470): zero the sum buffer and frame count. */
+int rt_reset_accum(rt_ctx *ctx);
+
+/* Blocks until all queued work on the context's stream is complete. */
+int rt_sync(rt_ctx *ctx);
+
+/* Reads the sum buffer (W*H*4 floats, row 0 = bottom row as gl_FragCoord) and the
+ * number of frames added.  mean = sum / frames is what getCurrentFrame()
+ * (src/RayTracer.h:39) holds in the reference.  Synchronises. */
+int rt_readback(rt_ctx *ctx, float *rgba_sum, size_t floats, uint32_t *frames);
+
+/* Device pointer of the sum buffer, for an in-place RCCL reduce by the caller. */
+int rt_accum_device_ptr(rt_ctx *ctx, void **dev_ptr, size_t *floats);
+/* Makes the context accumulate into caller-owned device memory (W*H*4 floats). */
+int rt_bind_accum(rt_ctx *ctx, void *dev_ptr, size_t floats);
+/* Adds `frames` to the frame count after an external reduce merged other ranks' sums. */
+int rt_add_frames(rt_ctx *ctx, uint32_t frames);
+
+/* Parity hook (no reference counterpart: the reference never outputs IDs): closest
+ * hit of the first camera sample's ray of frame `frame`, sample index 0, per pixel.
+ * model = index in the model-info stream or -1; ident = identifier index inside
+ * that model (leaf order) or, when model == -2, the primitive index; t,u,v as
+ * hitTriangle computes them (src/RayScene.cpp:540-544).  Host arrays of W*H. */
+int rt_trace_primary(rt_ctx *ctx, uint32_t frame, int32_t *model, int32_t *ident,
+                     float *t, float *u, float *v);
+
+int rt_get_stats(rt_ctx *ctx, rt_stats *out);
+int rt_reset_stats(rt_ctx *ctx);
+/* Enables per-ray node/triangle visit counting (slower; off by default). */
+int rt_set_counters(rt_ctx *ctx, int enabled);
+
+const char *rt_strerror(int status);
+const char *rt_last_hip_error(rt_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_HIP_H */

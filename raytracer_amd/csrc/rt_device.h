@@ -1,0 +1,332 @@
+// rt_device.h — device-side data layout and scene decode for the HIP backend.
+//
+// Two views of the scene live in HBM:
+//   * the five raw word streams exactly as the host serialised them (used by the
+//     shading kernels, which touch each hit once), and
+//   * a traversal re-pack built at commit time: 64-byte inner nodes holding both
+//     child boxes, and 48-byte triangle records (A, B-A, C-A + ids).
+// Every function cites the reference GLSL it reproduces (paths in the reference tree).
+#pragma once
+
+#include "rt_math.h"
+
+namespace rtd {
+
+using namespace rtm;
+
+// ---- traversal re-pack ------------------------------------------------------------
+// Child reference: >= 0 -> index of an inner node in `nodes`;
+//                  <  0 -> leaf: ~ref = (firstTriangle << 2) | triangleCount.
+struct __attribute__((aligned(64))) PackedNode {
+    float lmin[3]; int32_t left;
+    float lmax[3]; int32_t right;
+    float rmin[3]; int32_t pad0;
+    float rmax[3]; int32_t pad1;
+};
+static_assert(sizeof(PackedNode) == 64, "inner node must be one 64-byte line");
+
+struct __attribute__((aligned(16))) PackedTri {
+    float a[3];  int32_t material;   // vertex A,   scene-wide material index
+    float ab[3]; int32_t model;      // B - A,      model slot | flags (kTriAlphaTest)
+    float ac[3]; int32_t ident;      // C - A,      identifier index inside the model (leaf order)
+};
+static_assert(sizeof(PackedTri) == 48, "triangle record must be 48 bytes");
+constexpr int32_t kTriAlphaTest = 1 << 30;  // triangle needs the alpha-cut texture test
+constexpr int32_t kTriModelMask = (1 << 30) - 1;
+
+struct ModelDesc {
+    int32_t rootRef;            // child reference of node 0
+    int32_t nodesCount, identifiersCount, lightSourcesCount;
+    int32_t lightBase;          // word offset of the light identifiers (the info stream's location)
+    int32_t nodeBase;           // word offset of node 0
+    int32_t identBase;          // word offset of identifier 0
+    int32_t vertBase;           // word offset of vertex 0
+    int32_t triBase;            // index of identifier 0 in the packed triangle array
+    int32_t pad[3];
+};
+
+struct SceneView {
+    const float *objects, *materials, *modelInfo, *models, *textures;
+    const PackedNode *nodes;
+    const PackedTri *tris;
+    const ModelDesc *modelDesc;
+    int32_t objectCount, modelsCount, lightSourcesCount;
+};
+
+// Hit record written by the traversal kernel: 16 bytes.
+//   id == kMiss            : nothing hit (t = 1e20)
+//   id & kPrimBit          : analytic primitive, index = id & kIndexMask
+//   otherwise              : packed triangle index = id & kIndexMask;
+//                            kNoTexBit set when the model hit only TIED the
+//                            closest primitive, so textures are not applied
+//                            (the `startClosest > closest` test of src/RayScene.cpp:763).
+struct __attribute__((aligned(16))) HitRec {
+    float t, u, v;
+    uint32_t id;
+};
+constexpr uint32_t kMiss = 0xffffffffu;
+constexpr uint32_t kPrimBit = 0x80000000u;
+constexpr uint32_t kNoTexBit = 0x40000000u;
+constexpr uint32_t kIndexMask = 0x3fffffffu;
+
+struct __attribute__((aligned(16))) RayRec {
+    float ox, oy, oz, pad0;
+    float dx, dy, dz, pad1;
+};
+
+struct V2 { float x, y; };
+RT_FN V2 v2(float x, float y) { V2 r; r.x = x; r.y = y; return r; }
+RT_FN V2 operator*(float s, V2 a) { return v2(s * a.x, s * a.y); }
+RT_FN V2 operator+(V2 a, V2 b) { return v2(a.x + b.x, a.y + b.y); }
+RT_FN V2 operator-(V2 a, V2 b) { return v2(a.x - b.x, a.y - b.y); }
+
+constexpr float kMinDenominator = 1e-8f;   // MIN_DENOMINATOR, src/RayTracer.cpp:29
+constexpr float kPi = 3.1415926f;          // src/RayTracer.cpp:31-33
+constexpr float kInvPi = 1.0f / kPi;
+constexpr float kRad = kPi / 180.0f;
+constexpr int kIdentWords = 5;             // src/RayScene.cpp:674-675
+constexpr int kNodeWords = 9;
+constexpr int kMaterialWords = 23;         // 92 / 4, src/RayScene.cpp:387
+
+// ---- raw stream access --------------------------------------------------------------
+RT_FN float ldw(const float *s, int i) { return s[i]; }
+RT_FN int32_t ldi(const float *s, int i) { return f2i(s[i]); }
+RT_FN V3 ld3(const float *s, int i) { return v3(s[i], s[i + 1], s[i + 2]); }
+RT_FN V2 ld2(const float *s, int i) { return v2(s[i], s[i + 1]); }
+
+struct MaterialD {
+    int32_t normalTexture, baseColorTexture, metallicRoughnessTexture, emissiveTexture, transmissionTexture, occlusionTexture;
+    V3 emissionColor;
+    float emissionStrength;
+    V3 albedo;
+    float subsurface, roughness, metallic, specular, specularTint, transmission, ior, alphaCut, normalScale, occlusionStrength;
+};
+
+// loadMaterial, src/RayScene.cpp:383-415
+RT_FN MaterialD loadMaterial(const SceneView &sc, int materialIndex) {
+    const float *m = sc.materials + materialIndex * kMaterialWords;
+    MaterialD r;
+    r.normalTexture = f2i(m[0]);
+    r.baseColorTexture = f2i(m[1]);
+    r.metallicRoughnessTexture = f2i(m[2]);
+    r.emissiveTexture = f2i(m[3]);
+    r.transmissionTexture = f2i(m[4]);
+    r.occlusionTexture = f2i(m[5]);
+    r.emissionColor = v3(m[6], m[7], m[8]);
+    r.emissionStrength = m[9];
+    r.albedo = v3(m[10], m[11], m[12]);
+    r.subsurface = m[13];
+    r.roughness = m[14];
+    r.metallic = m[15];
+    r.specular = m[16];
+    r.specularTint = m[17];
+    r.transmission = m[18];
+    r.ior = m[19];
+    r.alphaCut = m[20];
+    r.normalScale = m[21];
+    r.occlusionStrength = m[22];
+    return r;
+}
+
+// srgb_to_linear, src/RayScene.cpp:268-277
+RT_FN float srgbToLinear(float c) {
+    if (c <= 0.04045f) return c / 12.92f;
+    return pow_((c + 0.055f) / 1.055f, 2.4f);
+}
+
+// getTextureUV + getTextureItemIndex, src/RayScene.cpp:337-380.  `header` is the
+// word offset of the 5-word texture header; returns the word offset of the texel.
+RT_FN float wrapCoord(int mode, float x) {
+    if (mode == 10497) return fract_(x);
+    if (mode == 33071) return clamp_(x, 0.0f, 1.0f);
+    if (mode == 33648) {
+        float t = fract_(x * 0.5f) * 2.0f;
+        return t > 1.0f ? 2.0f - t : t;
+    }
+    return x;
+}
+RT_FN int texelOffset(const SceneView &sc, int header, V2 uv) {
+    const float *h = sc.textures + header;
+    int width = f2i(h[0]), height = f2i(h[1]), channels = f2i(h[2]), wrapS = f2i(h[3]), wrapT = f2i(h[4]);
+    float x = clamp_(wrapCoord(wrapS, uv.x), 0.0f, 0.999999f);
+    float y = clamp_(wrapCoord(wrapT, uv.y), 0.0f, 0.999999f);
+    return header + 5 + ((int)(x * (float)width) + (int)(y * (float)height) * width) * channels;
+}
+
+// Barycentric UV interpolation used for texturing (Cramer form, src/RayScene.cpp:764-780).
+RT_FN V2 cramerUV(V3 a, V3 b, V3 c, V2 ta, V2 tb, V2 tc, V3 p) {
+    V3 e0 = b - a, e1 = c - a, vp = p - a;
+    float d00 = dot(e0, e0), d01 = dot(e0, e1), d11 = dot(e1, e1), d20 = dot(vp, e0), d21 = dot(vp, e1);
+    float denom = d00 * d11 - d01 * d01;
+    float v = (d11 * d20 - d01 * d21) / denom;
+    float w = (d00 * d21 - d01 * d20) / denom;
+    float u = 1.0f - v - w;
+    return u * ta + v * tb + w * tc;
+}
+
+// ---- resolved hit (what `hit()` leaves in HitInfo, src/RayScene.cpp:847-898) -------
+struct HitInfoD {
+    V3 point, normal;
+    float t, area;
+    int32_t modelLightCounts;
+    bool front_face;
+    bool isPrimitive;
+    MaterialD mat;
+};
+
+struct TriVerts {
+    V3 p[3], n[3];
+    V2 uv[3];
+};
+RT_FN void loadTriVerts(const SceneView &sc, int vertBase, const int32_t idx[3], TriVerts &tv) {
+    for (int k = 0; k < 3; ++k) {
+        const float *v = sc.models + vertBase + idx[k] * 8;
+        tv.p[k] = v3(v[0], v[1], v[2]);
+        tv.n[k] = v3(v[3], v[4], v[5]);
+        tv.uv[k] = v2(v[6], v[7]);
+    }
+}
+
+// Shading normal of a triangle hit (hitTriangle, src/RayScene.cpp:582-595).
+RT_FN V3 triangleNormal(V3 n0, V3 n1, V3 n2, V3 geometric, float u, float v) {
+    if (dot(n0, n0) > 0.0f) {
+        float w = 1.0f - u - v;
+        return normalize(n0 * w + n1 * u + n2 * v);
+    }
+    return normalize(geometric);
+}
+
+// Rebuilds the full HitInfo of a recorded hit.  The record must not be a miss.
+RT_FN HitInfoD resolveHit(const SceneView &sc, V3 ro, V3 rd, const HitRec &h) {
+    HitInfoD info;
+    info.t = h.t;
+    info.point = ro + h.t * rd;   // rayAt
+    info.area = 0.0f;
+    info.modelLightCounts = 0;
+    info.isPrimitive = (h.id & kPrimBit) != 0u;
+
+    if (info.isPrimitive) {
+        // Walk the variable-length primitive stream to record `index` (src/RayScene.cpp:855-891).
+        int want = (int)(h.id & kIndexMask);
+        int at = 0, type = 0, material = 0;
+        for (int i = 0;; ++i) {
+            type = ldi(sc.objects, at);
+            material = ldi(sc.objects, at + 1);
+            at += 2;
+            if (i == want) break;
+            at += (type == 0) ? 4 : (type == 1) ? 10 : (type == 2) ? 18 : 0;
+        }
+        if (type == 0) {            // hitSphere, src/RayScene.cpp:461-464
+            V3 center = ld3(sc.objects, at);
+            float radius = ldw(sc.objects, at + 3);
+            info.normal = normalize((info.point - center) / radius);
+        } else if (type == 1) {     // hitQuad, src/RayScene.cpp:480-506
+            V3 qu = ld3(sc.objects, at + 3), qv = ld3(sc.objects, at + 6);
+            V3 normal = cross(qu, qv);
+            float denom = dot(normal, rd);
+            info.normal = denom < 0.0f ? normalize(normal) : -normalize(normal);
+        } else {                    // top-level Triangle, src/RayScene.cpp:511-523
+            V3 a = ld3(sc.objects, at), b = ld3(sc.objects, at + 3), c = ld3(sc.objects, at + 6);
+            V3 n0 = ld3(sc.objects, at + 9), n1 = ld3(sc.objects, at + 12), n2 = ld3(sc.objects, at + 15);
+            info.normal = triangleNormal(n0, n1, n2, cross(b - a, c - a), h.u, h.v);
+        }
+        info.front_face = dot(rd, info.normal) < 0.0f;
+        info.mat = loadMaterial(sc, material);
+        return info;
+    }
+
+    const PackedTri &pt = sc.tris[h.id & kIndexMask];
+    const ModelDesc &md = sc.modelDesc[pt.model & kTriModelMask];
+    const float *idw = sc.models + md.identBase + pt.ident * kIdentWords;
+    int32_t idx[3] = {f2i(idw[0]), f2i(idw[1]), f2i(idw[2])};
+    int materialIndex = f2i(idw[3]);
+    bool hasTextures = idw[4] != 0.0f;
+    TriVerts tv;
+    loadTriVerts(sc, md.vertBase, idx, tv);
+
+    V3 edgeAB = tv.p[1] - tv.p[0], edgeAC = tv.p[2] - tv.p[0];
+    V3 geometric = cross(edgeAB, edgeAC);
+    info.normal = triangleNormal(tv.n[0], tv.n[1], tv.n[2], geometric, h.u, h.v);
+    info.front_face = dot(rd, info.normal) < 0.0f;
+    info.area = 0.5f * length(geometric);                       // triArea, src/RayScene.cpp:677-679
+    info.modelLightCounts = md.lightSourcesCount;
+    info.mat = loadMaterial(sc, materialIndex);
+
+    if (hasTextures && (h.id & kNoTexBit) == 0u) {                 // src/RayScene.cpp:763-844
+        V2 uv = cramerUV(tv.p[0], tv.p[1], tv.p[2], tv.uv[0], tv.uv[1], tv.uv[2], info.point);
+        MaterialD &m = info.mat;
+        if (m.baseColorTexture != -1) {
+            int at = texelOffset(sc, m.baseColorTexture, uv);
+            m.albedo = v3(srgbToLinear(sc.textures[at]), srgbToLinear(sc.textures[at + 1]), srgbToLinear(sc.textures[at + 2]));
+            m.transmission *= 1.0f - sc.textures[at + 3];
+        }
+        if (m.metallicRoughnessTexture != -1) {
+            int at = texelOffset(sc, m.metallicRoughnessTexture, uv);
+            m.roughness *= sc.textures[at + 1];
+            m.metallic *= sc.textures[at + 2];
+        }
+        if (m.normalTexture != -1) {
+            // Tangent frame from the triangle's UVs (src/RayScene.cpp:597-621); the
+            // normal map is skipped when they do not define one.
+            V2 d1 = tv.uv[1] - tv.uv[0], d2 = tv.uv[2] - tv.uv[0];
+            float uvDet = d1.x * d2.y - d2.x * d1.y;
+            if (abs_(uvDet) > kMinDenominator) {
+                float f = 1.0f / uvDet;
+                V3 tangent = v3(f * (d2.y * edgeAB.x - d1.y * edgeAC.x), f * (d2.y * edgeAB.y - d1.y * edgeAC.y),
+                                f * (d2.y * edgeAB.z - d1.y * edgeAC.z));
+                tangent = tangent - dot(tangent, info.normal) * info.normal;
+                if (length(tangent) > kMinDenominator) {
+                    tangent = normalize(tangent);
+                    V3 bitangent = cross(info.normal, tangent);
+                    int at = texelOffset(sc, m.normalTexture, uv);
+                    V3 tn = ld3(sc.textures, at) * 2.0f - v3s(1.0f);
+                    tn.x *= m.normalScale;
+                    tn.y *= m.normalScale;
+                    tn = normalize(tn);
+                    info.normal = normalize(tangent * tn.x + bitangent * tn.y + info.normal * tn.z);
+                    info.front_face = dot(rd, info.normal) < 0.0f;
+                }
+            }
+        }
+        if (m.emissiveTexture != -1) {
+            int at = texelOffset(sc, m.emissiveTexture, uv);
+            m.emissionColor = m.emissionColor * ld3(sc.textures, at);
+        }
+        if (m.transmissionTexture != -1) {
+            int at = texelOffset(sc, m.transmissionTexture, uv);
+            m.transmission *= sc.textures[at];
+        }
+        if (m.occlusionTexture != -1) {
+            int at = texelOffset(sc, m.occlusionTexture, uv);
+            m.transmission *= 1.0f - (1.0f - sc.textures[at]) * (1.0f - m.occlusionStrength);
+        }
+    }
+    return info;
+}
+
+// sampleRandomPointFromLightSouces, src/RayScene.cpp:900-935.  Four draws when
+// any light model exists, none otherwise.
+RT_FN V3 sampleLightPoint(const SceneView &sc, uint32_t &seed, float &area, float &lightTriangleCount) {
+    if (sc.lightSourcesCount == 0) {
+        area = 0.0f;
+        lightTriangleCount = 0.0f;
+        return v3s(0.0f);
+    }
+    int pick = (int)(rand_u32(seed) % (uint32_t)sc.lightSourcesCount);
+    const ModelDesc &md = sc.modelDesc[pick];
+    lightTriangleCount = (float)md.lightSourcesCount;
+    int identAt = md.lightBase + (int)(rand_u32(seed) % (uint32_t)md.lightSourcesCount) * kIdentWords;
+    int32_t idx[3] = {ldi(sc.models, identAt), ldi(sc.models, identAt + 1), ldi(sc.models, identAt + 2)};
+    TriVerts tv;
+    loadTriVerts(sc, md.vertBase, idx, tv);
+    float r1 = rand_float(seed);
+    float r2 = rand_float(seed);
+    if (r1 + r2 > 1.0f) {
+        r1 = 1.0f - r1;
+        r2 = 1.0f - r2;
+    }
+    area = 0.5f * length(cross(tv.p[1] - tv.p[0], tv.p[2] - tv.p[0]));
+    return r1 * tv.p[0] + r2 * tv.p[1] + (1.0f - r1 - r2) * tv.p[2];
+}
+
+}  // namespace rtd

@@ -1,0 +1,1540 @@
+// rt_hip.hip — wavefront path tracer for gfx950 (MI355X) behind the C ABI of
+// include/rt_hip.h.
+//
+// Pipeline per batch of camera samples (all kernels on one stream, queue
+// lengths stay on the device, no host round trip inside a batch):
+//
+//   k_generate         camera rays + path state                  (1 thread / path)
+//   for bounce b = 0..bounces
+//     k_trace          closest hit for {extension rays of b} U {shadow rays of b-1}
+//     k_connect        NEE contribution of the shadow rays of b-1
+//     k_shade_*        material, emission/MIS, lobe sampling, NEE ray, Russian roulette;
+//                      survivors are compacted into the next queue (wave64 ballot +
+//                      one atomic per wave)
+//   k_trace/k_connect  shadow rays of the last bounce
+//   k_resolve          per pixel, samples added in sample order -> sum buffer
+//
+// k_trace is a persistent kernel: each wave pulls 64 rays at a time from the
+// queue, walks the per-model BVH2 with 64-byte node loads and keeps its
+// traversal stack in LDS ([entry][lane], conflict free).  Traversal order,
+// strictness of every comparison and the push-time-only culling follow
+// hitModel (reference src/RayScene.cpp:681-736), so the winner of a distance
+// tie is the one the reference would report.
+//
+// Build with -ffp-contract=off (see rt_math.h).
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "rt_hip.h"
+#include "rt_bsdf.h"
+
+using namespace rtd;
+
+namespace {
+
+constexpr int kStackDepth = 32;      // int stack[32], src/RayScene.cpp:682
+constexpr int kBlock = 256;
+constexpr int kMaxBounces = 62;      // stages kept on the device
+constexpr uint32_t kDefaultMaxPaths = 8u << 20;
+
+// Per-frame uniforms plus values derived from them once on the host.
+struct FrameParams {
+    float fov, resX, resY;
+    V3 position, forward, right, up;
+    int32_t bounces, rayPerPixel;
+    V3 sky;
+    // fragment main(), src/RayTracer.cpp:545-563
+    float rImgX, rImgY, focalLength, halfWidth, halfHeight;
+    int32_t ssq;
+    float rssq, wlDt, wlPdf;
+    int32_t W, H, tilesX, tilesY;
+    uint32_t npt;       // padded pixels per sample plane: tilesX*tilesY*64
+    uint32_t S;         // samples per frame = ssq*ssq
+};
+
+struct Batch {
+    uint32_t g0;         // first global sample index (frame-major, sample-minor)
+    uint32_t K;          // sample planes in this batch
+    uint32_t firstFrame, frameStride;
+    uint32_t P;          // capacity in paths; shadow-ray slots start at P
+};
+
+// Queue lengths and work cursors of one bounce, all device resident.
+struct Stage {
+    uint32_t nExt;       // extension rays entering this bounce
+    uint32_t nShadow;    // shadow rays produced by the previous bounce
+    uint32_t cursor;     // persistent-kernel work cursor
+    uint32_t pad;
+};
+
+struct PathBuffers {
+    RayRec *rays;        // [2P]  extension rays [0,P), shadow rays [P,2P)
+    HitRec *hits;        // [2P]
+    float4 *stA;         // [P]   RGB: throughput.rgb, prevBrdfPdf      Spectral: throughput, prevBrdfPdf, lambda, -
+    float4 *stB;         // [P]   RGB: radiance.rgb, seed bits          Spectral: radiance, -, -, seed bits
+    float4 *neeA, *neeB, *neeC;   // [P] pending NEE term of the current bounce
+    uint32_t *qExt[2];   // [P] each, ping-pong by bounce parity
+    uint32_t *qShadow;   // [P]
+    Stage *stages;       // [kMaxBounces + 2]
+    unsigned long long *counters;  // [8]: 0 rays, 1 nodeVisits, 2 triTests, 3 shadedHits
+};
+
+__device__ __forceinline__ uint32_t laneId() { return threadIdx.x & 63u; }
+
+// Appends `value` for every lane with `want`; one atomic per wave.  Must be
+// called by all lanes of the wave.
+__device__ __forceinline__ void wavePush(bool want, uint32_t *queue, uint32_t *count, uint32_t value) {
+    unsigned long long mask = __ballot(want);
+    if (mask == 0ull) return;
+    uint32_t lane = laneId();
+    int leader = __ffsll((long long)mask) - 1;
+    uint32_t base = 0;
+    if ((int)lane == leader) base = atomicAdd(count, (uint32_t)__popcll(mask));
+    base = __shfl(base, leader);
+    if (want) queue[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = value;
+}
+
+// Path index -> pixel.  64 consecutive paths form one 8x8 pixel tile so a wave
+// of primary rays is spatially compact.
+__device__ __forceinline__ bool pathPixel(const FrameParams &fp, uint32_t q, int &x, int &y) {
+    uint32_t tile = q >> 6, l = q & 63u;
+    x = (int)(tile % (uint32_t)fp.tilesX) * 8 + (int)(l & 7u);
+    y = (int)(tile / (uint32_t)fp.tilesX) * 8 + (int)(l >> 3);
+    return x < fp.W && y < fp.H;
+}
+
+// ---- k_generate -----------------------------------------------------------------------
+// Camera ray of fragment main() (src/RayTracer.cpp:559-578 / 1333-1366): jitter
+// in units of (1/W)*right and (1/H)*up, first draw horizontal.
+template <bool SPECTRAL>
+__global__ __launch_bounds__(kBlock) void k_generate(FrameParams fp, Batch bt, PathBuffers pb) {
+    const uint32_t total = bt.K * fp.npt;
+    const uint32_t stride = gridDim.x * kBlock;
+    for (uint32_t base = blockIdx.x * kBlock + (threadIdx.x & ~63u); base < total; base += stride) {
+        uint32_t p = base + laneId();
+        bool valid = false;
+        if (p < total) {
+            uint32_t k = p / fp.npt, q = p - k * fp.npt;
+            int x, y;
+            valid = pathPixel(fp, q, x, y);
+            if (valid) {
+                uint32_t g = bt.g0 + k;
+                uint32_t frame = bt.firstFrame + (g / fp.S) * bt.frameStride;
+                uint32_t s = g % fp.S;
+                int i = (int)(s / (uint32_t)fp.ssq), j = (int)(s % (uint32_t)fp.ssq);
+                uint32_t seed = hash_seed((uint32_t)x, (uint32_t)y, frame, s);
+
+                float ux = (float)x * fp.rImgX * 2.0f - 1.0f;
+                float uy = (float)y * fp.rImgY * 2.0f - 1.0f;
+                V3 uv = fp.halfWidth * ux * fp.right + fp.halfHeight * uy * fp.up + fp.focalLength * fp.forward + fp.position;
+                float jx = rand_float(seed);
+                float jy = rand_float(seed);
+                V3 d = uv + (((float)j + jx) * fp.rssq) * fp.rImgX * fp.right + (((float)i + jy) * fp.rssq) * fp.rImgY * fp.up;
+                d = normalize(d - fp.position);
+
+                RayRec r;
+                r.ox = fp.position.x; r.oy = fp.position.y; r.oz = fp.position.z; r.pad0 = 0.0f;
+                r.dx = d.x; r.dy = d.y; r.dz = d.z; r.pad1 = 0.0f;
+                pb.rays[p] = r;
+                if (SPECTRAL) {
+                    float lambda = (rand_float(seed) + (float)(i * fp.ssq) + (float)j) * fp.wlDt + kWlMin;
+                    pb.stA[p] = make_float4(1.0f, 1.0f, lambda, 0.0f);
+                    pb.stB[p] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(seed));
+                } else {
+                    pb.stA[p] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+                    pb.stB[p] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(seed));
+                }
+            }
+        }
+        wavePush(valid, pb.qExt[0], &pb.stages[0].nExt, p);
+    }
+}
+
+// ---- k_trace ----------------------------------------------------------------------------
+// RayBoundingBoxDst, src/RayScene.cpp:417-431, with 1/direction hoisted per ray.
+__device__ __forceinline__ float slabDistance(V3 bmin, V3 bmax, V3 ro, V3 inv, float t) {
+    V3 tMin = (bmin - ro) * inv;
+    V3 tMax = (bmax - ro) * inv;
+    V3 t1 = vmin(tMin, tMax);
+    V3 t2 = vmax(tMin, tMax);
+    float nearD = fmax_(fmax_(t1.x, t1.y), t1.z);
+    if (nearD > t) return 1e20f;
+    float farD = fmin_(fmin_(t2.x, t2.y), t2.z);
+    return (farD >= nearD && farD > 0.0f) ? nearD : 1e20f;
+}
+
+// Alpha-cut rejection inside hitTriangle (src/RayScene.cpp:547-577).  Only
+// triangles flagged kTriAlphaTest at commit time come here.
+__device__ __noinline__ bool alphaCutRejects(const SceneView &sc, const PackedTri &pt, V3 ro, V3 rd, float t) {
+    const ModelDesc &md = sc.modelDesc[pt.model & kTriModelMask];
+    const float *idw = sc.models + md.identBase + pt.ident * kIdentWords;
+    int32_t idx[3] = {f2i(idw[0]), f2i(idw[1]), f2i(idw[2])};
+    TriVerts tv;
+    loadTriVerts(sc, md.vertBase, idx, tv);
+    const float *m = sc.materials + pt.material * kMaterialWords;
+    int baseColor = f2i(m[1]);
+    float alphaCut = m[20];
+    V2 uv = cramerUV(tv.p[0], tv.p[1], tv.p[2], tv.uv[0], tv.uv[1], tv.uv[2], ro + t * rd);
+    int at = texelOffset(sc, baseColor, uv);
+    return sc.textures[at + 3] < alphaCut;
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void k_trace(SceneView sc, PathBuffers pb, const uint32_t *qExt, int stage) {
+    __shared__ int32_t stackLds[kBlock / 64][kStackDepth][64];
+    const uint32_t lane = laneId();
+    int32_t(*stack)[64] = stackLds[threadIdx.x >> 6];
+
+    Stage *st = &pb.stages[stage];
+    const uint32_t nExt = qExt ? st->nExt : 0u;
+    const uint32_t n = nExt + st->nShadow;
+    uint32_t cntNodes = 0, cntTris = 0;
+
+    for (;;) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&st->cursor, 64u);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (base >= n) break;
+        const uint32_t i = base + lane;
+        if (i < n) {            // tail lanes idle until the wave's rays are done
+        const uint32_t slot = (i < nExt) ? qExt[i] : pb.qShadow[i - nExt];
+        const float4 *rp = reinterpret_cast<const float4 *>(&pb.rays[slot]);
+        const float4 r0 = rp[0], r1 = rp[1];
+        const V3 ro = v3(r0.x, r0.y, r0.z), rd = v3(r1.x, r1.y, r1.z);
+        const V3 inv = v3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+
+        float closest = 1e20f;
+        uint32_t bestId = kMiss;
+        float bestU = 0.0f, bestV = 0.0f;
+
+        // Analytic primitives, linear scan (hit(), src/RayScene.cpp:855-891).
+        int at = 0;
+        for (int pi = 0; pi < sc.objectCount; ++pi) {
+            const int type = ldi(sc.objects, at);
+            at += 2;
+            if (type == 0) {            // hitSphere, src/RayScene.cpp:441-466
+                V3 center = ld3(sc.objects, at);
+                float radius = ldw(sc.objects, at + 3);
+                at += 4;
+                V3 dir = center - ro;
+                float a = dot(rd, rd);
+                float h = dot(rd, dir);
+                float c = dot(dir, dir) - radius * radius;
+                float disc = h * h - a * c;
+                if (!(disc < 0.0f)) {
+                    float sq = sqrt_(disc);
+                    float t = (h - sq) / a;
+                    bool ok = true;
+                    if (t <= 1e-8f || t >= closest) {
+                        t = (h + sq) / a;
+                        if (t <= 1e-8f || t >= closest) ok = false;
+                    }
+                    if (ok) { closest = t; bestId = kPrimBit | (uint32_t)pi; bestU = 0.0f; bestV = 0.0f; }
+                }
+            } else if (type == 1) {     // hitQuad, src/RayScene.cpp:478-508 (+ cull, :870)
+                V3 qq = ld3(sc.objects, at), qu = ld3(sc.objects, at + 3), qv = ld3(sc.objects, at + 6);
+                bool cull = ldw(sc.objects, at + 9) != 0.0f;
+                at += 10;
+                V3 normal = cross(qu, qv);
+                if (!(cull && dot(rd, normal) > 0.0f)) {
+                    float denom = dot(normal, rd);
+                    float nn = dot(normal, normal);
+                    if (!(abs_(denom) < kMinDenominator)) {
+                        float t = dot(normal, qq - ro) / denom;
+                        if (!(t < 1e-8f || t > closest || t >= closest)) {
+                            V3 rel = (ro + t * rd) - qq;
+                            float alpha = dot(normal, cross(rel, qv)) / nn;
+                            float beta = dot(normal, cross(qu, rel)) / nn;
+                            if (!(alpha < 0.0f || alpha > 1.0f || beta < 0.0f || beta > 1.0f)) {
+                                closest = t; bestId = kPrimBit | (uint32_t)pi; bestU = 0.0f; bestV = 0.0f;
+                            }
+                        }
+                    }
+                }
+            } else if (type == 2) {     // top-level Triangle through hitTriangle
+                V3 A = ld3(sc.objects, at), B = ld3(sc.objects, at + 3), C = ld3(sc.objects, at + 6);
+                at += 18;
+                if (COUNT) cntTris++;
+                V3 ab = B - A, ac = C - A;
+                V3 nrm = cross(ab, ac);
+                float det = -dot(rd, nrm);
+                if (!(abs_(det) < 1e-8f)) {
+                    V3 ao = ro - A;
+                    V3 dao = cross(ao, rd);
+                    float invDet = 1.0f / det;
+                    float t = dot(ao, nrm) * invDet;
+                    if (!(t < 0.0f || t > closest || t >= closest)) {
+                        float u = dot(ac, dao) * invDet;
+                        float v = -dot(ab, dao) * invDet;
+                        if (!(u < 0.0f || v < 0.0f || u + v > 1.0f)) {
+                            closest = t; bestId = kPrimBit | (uint32_t)pi; bestU = u; bestV = v;
+                        }
+                    }
+                }
+            }
+        }
+        const float afterPrimitives = closest;
+
+        // Models in info-stream order (hitModels, src/RayScene.cpp:746-760).
+        for (int m = 0; m < sc.modelsCount; ++m) {
+            const ModelDesc md = sc.modelDesc[m];
+            if (md.nodesCount <= 0) continue;
+            float tModel = 1e20f;      // hInfo.t
+            float maxT = closest;      // `max` argument
+            uint32_t mBest = kMiss;
+            float mU = 0.0f, mV = 0.0f;
+            int sp = 0;
+            int32_t ref = md.rootRef;
+
+            for (;;) {
+                if (ref >= 0) {
+                    if (COUNT) cntNodes++;
+                    const float4 *np = reinterpret_cast<const float4 *>(&sc.nodes[ref]);
+                    const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+                    const int32_t left = __float_as_int(n0.w), right = __float_as_int(n1.w);
+                    const float dL = slabDistance(v3(n0.x, n0.y, n0.z), v3(n1.x, n1.y, n1.z), ro, inv, tModel);
+                    const float dR = slabDistance(v3(n2.x, n2.y, n2.z), v3(n3.x, n3.y, n3.z), ro, inv, tModel);
+                    const bool pushL = dL < tModel, pushR = dR < tModel;
+                    // The child pushed last is popped first: left when dL < dR, else right.
+                    if (dL < dR) {
+                        if (pushL) {
+                            if (pushR) { if (sp < kStackDepth) stack[sp++][lane] = right; }
+                            ref = left;
+                            continue;
+                        }
+                        if (pushR) { ref = right; continue; }
+                    } else {
+                        if (pushR) {
+                            if (pushL) { if (sp < kStackDepth) stack[sp++][lane] = left; }
+                            ref = right;
+                            continue;
+                        }
+                        if (pushL) { ref = left; continue; }
+                    }
+                } else {
+                    const uint32_t code = ~(uint32_t)ref;
+                    const uint32_t first = code >> 2, count = code & 3u;
+                    for (uint32_t k = 0; k < count; ++k) {
+                        if (COUNT) cntTris++;
+                        const uint32_t ti = first + k;
+                        const float4 *tp = reinterpret_cast<const float4 *>(&sc.tris[ti]);
+                        const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
+                        const V3 A = v3(q0.x, q0.y, q0.z), ab = v3(q1.x, q1.y, q1.z), ac = v3(q2.x, q2.y, q2.z);
+                        const V3 nrm = cross(ab, ac);
+                        const float det = -dot(rd, nrm);
+                        if (abs_(det) < 1e-8f) continue;
+                        const V3 ao = ro - A;
+                        const V3 dao = cross(ao, rd);
+                        const float invDet = 1.0f / det;
+                        const float t = dot(ao, nrm) * invDet;
+                        if (t < 0.0f || t > maxT || t >= tModel) continue;
+                        const float u = dot(ac, dao) * invDet;
+                        const float v = -dot(ab, dao) * invDet;
+                        if (u < 0.0f || v < 0.0f || u + v > 1.0f) continue;
+                        if (__float_as_int(q1.w) & kTriAlphaTest) {
+                            if (alphaCutRejects(sc, sc.tris[ti], ro, rd, t)) continue;
+                        }
+                        tModel = t;
+                        maxT = t;
+                        mBest = ti;
+                        mU = u;
+                        mV = v;
+                    }
+                }
+                if (sp == 0) break;
+                ref = stack[--sp][lane];
+            }
+            if (mBest != kMiss) {
+                closest = tModel;
+                bestId = mBest;
+                bestU = mU;
+                bestV = mV;
+            }
+        }
+        if (bestId != kMiss && (bestId & kPrimBit) == 0u && !(afterPrimitives > closest)) bestId |= kNoTexBit;
+
+        HitRec rec;
+        rec.t = closest;
+        rec.u = bestU;
+        rec.v = bestV;
+        rec.id = bestId;
+        *reinterpret_cast<float4 *>(&pb.hits[slot]) = *reinterpret_cast<const float4 *>(&rec);
+        }
+    }
+
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&pb.counters[0], (unsigned long long)n);
+    if (COUNT) {
+        atomicAdd(&pb.counters[1], (unsigned long long)cntNodes);
+        atomicAdd(&pb.counters[2], (unsigned long long)cntTris);
+    }
+}
+
+// ---- shading ---------------------------------------------------------------------------
+struct ShadowHit {
+    V3 normal;       // s_info.normal (unflipped)
+    bool frontFace;
+    float t;
+    V3 emissionColor;
+    float emissionStrength;
+};
+
+// State of the shadow ray's closest hit.  A miss leaves the zero-initialised
+// HitInfo with the default material 0 (the pinned reading of the
+// uninitialised `s_info`, src/RayTracer.cpp:435-439).
+__device__ __forceinline__ ShadowHit shadowHitOf(const SceneView &sc, const RayRec &sr, const HitRec &h, unsigned long long *counters) {
+    ShadowHit s;
+    if (h.id == kMiss) {
+        MaterialD m0 = loadMaterial(sc, 0);
+        s.normal = v3s(0.0f);
+        s.frontFace = false;
+        s.t = 1e20f;
+        s.emissionColor = m0.emissionColor;
+        s.emissionStrength = m0.emissionStrength;
+    } else {
+        HitInfoD info = resolveHit(sc, v3(sr.ox, sr.oy, sr.oz), v3(sr.dx, sr.dy, sr.dz), h);
+        s.normal = info.normal;
+        s.frontFace = info.front_face;
+        s.t = info.t;
+        s.emissionColor = info.mat.emissionColor;
+        s.emissionStrength = info.mat.emissionStrength;
+    }
+    (void)counters;
+    return s;
+}
+
+// NEE connection (src/RayTracer.cpp:439-477 RGB, :1162-1200 Spectral) for the
+// shadow rays traced in `stage`; adds into the owning path's radiance.
+template <bool SPECTRAL>
+__global__ __launch_bounds__(kBlock) void k_connect(SceneView sc, Batch bt, PathBuffers pb, int stage) {
+    const uint32_t n = pb.stages[stage].nShadow;
+    uint32_t shaded = 0;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const uint32_t slot = pb.qShadow[i];
+        const uint32_t path = slot - bt.P;
+        const RayRec sr = pb.rays[slot];
+        const HitRec h = pb.hits[slot];
+        const ShadowHit s = shadowHitOf(sc, sr, h, pb.counters);
+        if (h.id != kMiss) shaded++;
+        const float4 a = pb.neeA[path], b = pb.neeB[path], c = pb.neeC[path];
+        const V3 sd = v3(sr.dx, sr.dy, sr.dz);
+        if (!SPECTRAL) {
+            const V3 brdfDirect = v3(a.x, a.y, a.z);
+            const float cosTheta = a.w;
+            const V3 rayColor = v3(b.x, b.y, b.z);
+            const float pdfArea = b.w, dist2 = c.x, pdfBrdfLd = c.y, distToLight = c.z;
+            if (s.emissionStrength > 0.0f && s.t >= distToLight - 1e-4f) {
+                V3 nl = s.normal;
+                if (!s.frontFace) nl = -nl;
+                nl = normalize(nl);
+                float cosThetaL = fmax_(dot(-sd, nl), 0.0f);
+                float G = cosThetaL / dist2;
+                float pdfNee = pdfArea / fmax_(G, kMinDenominator);
+                float wNee = (pdfNee * pdfNee) / fmax_(pdfNee * pdfNee + pdfBrdfLd * pdfBrdfLd, kMinDenominator);
+                V3 direct = brdfDirect * s.emissionColor * s.emissionStrength * cosTheta * G / pdfArea;
+                float4 sb = pb.stB[path];
+                V3 L = v3(sb.x, sb.y, sb.z) + rayColor * direct * wNee;
+                pb.stB[path] = make_float4(L.x, L.y, L.z, sb.w);
+            }
+        } else {
+            const float brdfDirect = a.x, cosTheta = a.y, pdf = a.z, dist2 = a.w;
+            const float pdfBrdfLd = b.x, distToLight = b.y, throughput = b.z, lambda = b.w;
+            if (s.emissionStrength > 0.0f && s.t <= distToLight + 0.01f) {
+                float cosThetaL = abs_(dot(-sd, normalize(s.normal)));
+                float G = cosThetaL / dist2;
+                float pdfNee = pdf / fmax_(G, kMinDenominator);
+                float wNee = (pdfNee * pdfNee) / fmax_(pdfNee * pdfNee + pdfBrdfLd * pdfBrdfLd, kMinDenominator);
+                float energy = reflectanceAt(lambda, s.emissionColor);
+                float direct = brdfDirect * energy * s.emissionStrength * cosTheta * G / pdf;
+                float4 sb = pb.stB[path];
+                sb.x = sb.x + throughput * direct * wNee;
+                pb.stB[path] = sb;
+            }
+        }
+        (void)c;
+    }
+    if (shaded) atomicAdd(&pb.counters[3], (unsigned long long)shaded);
+}
+
+// One bounce of traceColor (src/RayTracer.cpp:333-538) for every path in the stage's queue.
+__global__ __launch_bounds__(kBlock) void k_shade_rgb(SceneView sc, FrameParams fp, Batch bt, PathBuffers pb, int stage) {
+    const uint32_t n = pb.stages[stage].nExt;
+    const uint32_t *qIn = pb.qExt[stage & 1];
+    uint32_t *qOut = pb.qExt[(stage + 1) & 1];
+    Stage *next = &pb.stages[stage + 1];
+    const bool lastBounce = stage >= fp.bounces;
+    const uint32_t stride = gridDim.x * kBlock;
+    uint32_t shaded = 0;
+
+    for (uint32_t base = blockIdx.x * kBlock + (threadIdx.x & ~63u); base < n; base += stride) {
+        const uint32_t i = base + laneId();
+        bool wantShadow = false, wantExt = false;
+        uint32_t path = 0;
+        if (i < n) {
+            path = qIn[i];
+            const RayRec ray = pb.rays[path];
+            const HitRec h = pb.hits[path];
+            const float4 sA = pb.stA[path];
+            float4 sB = pb.stB[path];
+            V3 rayColor = v3(sA.x, sA.y, sA.z);
+            float prevBrdfPdf = sA.w;
+            V3 incoming = v3(sB.x, sB.y, sB.z);
+            uint32_t seed = __float_as_uint(sB.w);
+            const V3 ro = v3(ray.ox, ray.oy, ray.oz), rd = v3(ray.dx, ray.dy, ray.dz);
+
+            if (h.id == kMiss) {                                    // sky, :338-344
+                float t = rd.y * 0.5f + 0.5f;
+                V3 env = (1.0f - t) * v3s(1.0f) + t * fp.sky;
+                if (dot(fp.sky, fp.sky) > 0.0f) incoming = incoming + env * rayColor;
+                pb.stB[path] = make_float4(incoming.x, incoming.y, incoming.z, sB.w);
+            } else {
+                shaded++;
+                HitInfoD info = resolveHit(sc, ro, rd, h);
+                V3 N = normalize(info.normal);
+                const V3 V = normalize(-rd);
+                if (!info.front_face) N = -N;
+                const MaterialD &mat = info.mat;
+
+                if (dot(mat.emissionColor, mat.emissionColor) > 0.0f && mat.emissionStrength > 0.0f) {   // :356-378
+                    if (stage == 0) {
+                        incoming = incoming + rayColor * mat.emissionColor * mat.emissionStrength;
+                    } else {
+                        float wBrdf;
+                        if (info.isPrimitive) {
+                            wBrdf = 1.0f;   // analytic emitters are never light-sampled
+                        } else {
+                            float pdfArea = 1.0f / info.area / (float)sc.lightSourcesCount / (float)info.modelLightCounts;
+                            float cosTheta = fmax_(dot(V, N), 0.0f);
+                            float pdfNee = pdfArea * (info.t * info.t) / fmax_(cosTheta, kMinDenominator);
+                            wBrdf = (prevBrdfPdf * prevBrdfPdf) / fmax_(prevBrdfPdf * prevBrdfPdf + pdfNee * pdfNee, kMinDenominator);
+                        }
+                        incoming = incoming + rayColor * wBrdf * mat.emissionColor * mat.emissionStrength;
+                    }
+                    pb.stB[path] = make_float4(incoming.x, incoming.y, incoming.z, sB.w);
+                } else {
+                    SurfaceRGB surf = surfaceOf(mat);
+                    surf.roughness = fmax_(surf.roughness, 0.0005f);
+                    const LobeProbs lp = lobeProbabilities(mat);
+
+                    V3 L;
+                    const float Xi = rand_float(seed);
+                    float diff = 0.0f, spec = 0.0f, sss = 0.0f;
+                    bool trans = false;
+                    if (Xi < lp.diffuse) {
+                        L = sampleCosineHemisphere(N, seed);
+                        diff = 1.0f;
+                    } else if (Xi < lp.diffuse + lp.specular) {
+                        L = sampleSpecular<false>(N, V, surf.roughness, seed);
+                        spec = 1.0f;
+                    } else if (Xi < lp.diffuse + lp.specular + lp.transmission) {
+                        L = sampleTransmission<false>(N, V, info.front_face, mat.ior, surf.roughness, seed);
+                        trans = true;
+                    } else {
+                        L = sampleCosineHemisphere(N, seed);
+                        sss = 1.0f;
+                    }
+                    L = normalize(L);
+
+                    const V3 H = normalize(V + L);
+                    const float NoV = clamp_(dot(N, V), 0.0f, 1.0f);
+                    const float NoL = clamp_(dot(N, L), 0.0f, 1.0f);
+                    const float NoH = clamp_(dot(N, H), 0.0f, 1.0f);
+                    const float VoH = clamp_(dot(V, H), 0.0f, 1.0f);
+                    const float LoV = clamp_(dot(L, V), 0.0f, 1.0f);
+
+                    if (!trans) {                                   // NEE set-up, :421-437
+                        float area, lightTriangleCount;
+                        V3 p = sampleLightPoint(sc, seed, area, lightTriangleCount);
+                        if (area > 0.0f) {
+                            V3 so = info.point + N * 0.001f;
+                            V3 toLight = p - so;
+                            float distToLight = length(toLight);
+                            V3 sdir = toLight / distToLight;
+                            float cosTheta = dot(N, sdir);
+                            if (cosTheta > 0.0f) {
+                                V3 Hd = normalize(V + sdir);
+                                float NoLd = clamp_(dot(N, sdir), 0.0f, 1.0f);
+                                float NoHd = clamp_(dot(N, Hd), 0.0f, 1.0f);
+                                float VoHd = clamp_(dot(V, Hd), 0.0f, 1.0f);
+                                float LoVd = clamp_(dot(sdir, V), 0.0f, 1.0f);
+                                float pdfArea = 1.0f / area / (float)sc.lightSourcesCount / lightTriangleCount;
+                                float pdfBrdfLd = lp.diffuse * (NoLd * kInvPi) + lp.specular * specularPdfRGB(NoHd, NoV, surf.roughness) +
+                                                  lp.subsurface * (NoLd * kInvPi);
+                                V3 brdfDirect = lp.diffuse * evalDiffuseRGB(surf, NoLd, NoV, VoHd) +
+                                                lp.specular * evalSpecularRGB(surf, NoV, NoLd, NoHd, VoHd) +
+                                                lp.subsurface * evalSubsurfaceRGB(surf, NoLd, NoV, LoVd);
+                                RayRec sr;
+                                sr.ox = so.x; sr.oy = so.y; sr.oz = so.z; sr.pad0 = 0.0f;
+                                sr.dx = sdir.x; sr.dy = sdir.y; sr.dz = sdir.z; sr.pad1 = 0.0f;
+                                pb.rays[bt.P + path] = sr;
+                                pb.neeA[path] = make_float4(brdfDirect.x, brdfDirect.y, brdfDirect.z, cosTheta);
+                                pb.neeB[path] = make_float4(rayColor.x, rayColor.y, rayColor.z, pdfArea);
+                                pb.neeC[path] = make_float4(dot(toLight, toLight), pdfBrdfLd, distToLight, 0.0f);
+                                wantShadow = true;
+                            }
+                        }
+                    }
+
+                    V3 no = info.point + N * 0.001f;                // continue path, :484-537
+                    bool alive = true;
+                    if (trans) {
+                        no = info.point + L * 0.001f;
+                        if (!info.front_face) {
+                            V3 al = vmax(mat.albedo, v3s(kMinDenominator));
+                            V3 tr = v3(exp_(info.t * log_(al.x)), exp_(info.t * log_(al.y)), exp_(info.t * log_(al.z)));
+                            rayColor = rayColor * tr;
+                        }
+                        prevBrdfPdf = 1.0f;
+                    } else if (NoL < kMinDenominator) {
+                        alive = false;
+                    } else {
+                        V3 brdfSss = evalSubsurfaceRGB(surf, NoL, NoV, LoV);
+                        V3 brdfSpec = evalSpecularRGB(surf, NoV, NoL, NoH, VoH);
+                        V3 brdfDiff = evalDiffuseRGB(surf, NoL, NoV, VoH);
+                        float pSurf = 1.0f - lp.transmission;
+                        pSurf = (pSurf < 1e-8f) ? 0.0f : pSurf;
+                        float norm = (pSurf > 0.0f) ? 1.0f / pSurf : 1.0f;
+                        float pdfDiffRaw = (NoL * kInvPi) * norm;
+                        float pdfSpecRaw = specularPdfRGB(NoH, NoV, surf.roughness) * norm;
+                        float pdfSssRaw = NoL * kInvPi * norm;
+                        float pdfUsed = pdfDiffRaw * lp.diffuse * diff + pdfSpecRaw * lp.specular * spec + pdfSssRaw * lp.subsurface * sss;
+                        prevBrdfPdf = pdfDiffRaw * lp.diffuse + pdfSpecRaw * lp.specular + pdfSssRaw * lp.subsurface;
+                        V3 brdfTotal = (brdfSpec * spec + brdfDiff * diff + brdfSss * sss);
+                        V3 contribution = (brdfTotal * NoL) / fmax_(pdfUsed, kMinDenominator);
+                        rayColor = rayColor * contribution;
+                        float rr = fmin_(fmax_(rayColor.x, fmax_(rayColor.y, rayColor.z)), 0.95f);
+                        if (rand_float(seed) > rr) alive = false;
+                        else rayColor = rayColor / rr;
+                    }
+
+                    if (alive && !lastBounce) {
+                        RayRec nr;
+                        nr.ox = no.x; nr.oy = no.y; nr.oz = no.z; nr.pad0 = 0.0f;
+                        nr.dx = L.x; nr.dy = L.y; nr.dz = L.z; nr.pad1 = 0.0f;
+                        pb.rays[path] = nr;
+                        pb.stA[path] = make_float4(rayColor.x, rayColor.y, rayColor.z, prevBrdfPdf);
+                        pb.stB[path] = make_float4(incoming.x, incoming.y, incoming.z, __uint_as_float(seed));
+                        wantExt = true;
+                    }
+                }
+            }
+        }
+        wavePush(wantShadow, pb.qShadow, &next->nShadow, bt.P + path);
+        wavePush(wantExt, qOut, &next->nExt, path);
+    }
+    if (shaded) atomicAdd(&pb.counters[3], (unsigned long long)shaded);
+}
+
+// One bounce of traceColorWavelength (src/RayTracer.cpp:1056-1252).
+__global__ __launch_bounds__(kBlock) void k_shade_spectral(SceneView sc, FrameParams fp, Batch bt, PathBuffers pb, int stage) {
+    const uint32_t n = pb.stages[stage].nExt;
+    const uint32_t *qIn = pb.qExt[stage & 1];
+    uint32_t *qOut = pb.qExt[(stage + 1) & 1];
+    Stage *next = &pb.stages[stage + 1];
+    const bool lastBounce = stage >= fp.bounces;
+    const uint32_t stride = gridDim.x * kBlock;
+    uint32_t shaded = 0;
+
+    for (uint32_t base = blockIdx.x * kBlock + (threadIdx.x & ~63u); base < n; base += stride) {
+        const uint32_t i = base + laneId();
+        bool wantShadow = false, wantExt = false;
+        uint32_t path = 0;
+        if (i < n) {
+            path = qIn[i];
+            const RayRec ray = pb.rays[path];
+            const HitRec h = pb.hits[path];
+            const float4 sA = pb.stA[path];
+            float4 sB = pb.stB[path];
+            float throughput = sA.x, prevBrdfPdf = sA.y;
+            const float lambda = sA.z;
+            float radiance = sB.x;
+            uint32_t seed = __float_as_uint(sB.w);
+            const V3 ro = v3(ray.ox, ray.oy, ray.oz), rd = v3(ray.dx, ray.dy, ray.dz);
+
+            if (h.id == kMiss) {                                    // :1061-1069
+                float t = rd.y * 0.5f + 0.5f;
+                V3 env = (1.0f - t) * v3s(1.0f) + t * fp.sky;
+                if (dot(fp.sky, fp.sky) > 0.0f) radiance += reflectanceAt(lambda, env) * throughput;
+                sB.x = radiance;
+                pb.stB[path] = sB;
+            } else {
+                shaded++;
+                HitInfoD info = resolveHit(sc, ro, rd, h);
+                V3 N = normalize(info.normal);
+                const V3 V = normalize(-rd);
+                MaterialD &mat = info.mat;
+
+                if (dot(mat.emissionColor, mat.emissionColor) > 0.0f && mat.emissionStrength > 0.0f) {   // :1075-1093
+                    float energy = reflectanceAt(lambda, mat.emissionColor);
+                    if (stage == 0) {
+                        radiance += energy * throughput * mat.emissionStrength;
+                    } else {
+                        float wBrdf;
+                        if (info.isPrimitive) {
+                            wBrdf = 1.0f;
+                        } else {
+                            float pdfArea = 1.0f / info.area / (float)sc.lightSourcesCount / (float)info.modelLightCounts;
+                            float pdfNee = pdfArea * (info.t * info.t) / fmax_(abs_(dot(V, N)), kMinDenominator);
+                            wBrdf = (prevBrdfPdf * prevBrdfPdf) / fmax_(prevBrdfPdf * prevBrdfPdf + pdfNee * pdfNee, kMinDenominator);
+                        }
+                        radiance += energy * throughput * mat.emissionStrength * wBrdf;
+                    }
+                    sB.x = radiance;
+                    pb.stB[path] = sB;
+                } else {
+                    if (!info.front_face) N = -N;
+                    const float roughness = fmax_(mat.roughness, 0.001f);
+                    const LobeProbs lp = lobeProbabilities(mat);
+
+                    V3 L;
+                    const float Xi = rand_float(seed);
+                    float diff = 0.0f, spec = 0.0f, sss = 0.0f;
+                    bool trans = false;
+                    if (Xi < lp.diffuse) {
+                        L = sampleCosineHemisphere(N, seed);
+                        diff = 1.0f;
+                    } else if (Xi < lp.diffuse + lp.specular) {
+                        L = sampleSpecular<true>(N, V, roughness, seed);
+                        spec = 1.0f;
+                    } else if (Xi < lp.diffuse + lp.specular + lp.transmission) {
+                        // dispersion: ior + 0.03 * ((550/lambda)^2 - 1), :1122-1126
+                        float ior = mat.ior + 0.03f * (pow_(550.0f / lambda, 2.0f) - 1.0f);
+                        L = sampleTransmission<true>(N, V, info.front_face, ior, roughness, seed);
+                        trans = true;
+                    } else {
+                        L = sampleCosineHemisphere(N, seed);
+                        sss = 1.0f;
+                    }
+                    L = normalize(L);
+
+                    const V3 H = normalize(V + L);
+                    const float NoV = clamp_(dot(N, V), 0.0f, 1.0f);
+                    const float NoL = clamp_(dot(N, L), 0.0f, 1.0f);
+                    const float NoH = clamp_(dot(N, H), 0.0f, 1.0f);
+                    const float VoH = clamp_(dot(V, H), 0.0f, 1.0f);
+                    const float LoV = clamp_(dot(L, V), 0.0f, 1.0f);
+
+                    SurfaceSpectral surf;
+                    surf.albedo = reflectanceAt(lambda, mat.albedo);
+                    surf.roughness = roughness;
+                    surf.metallic = mat.metallic;
+                    surf.specular = mat.specular;
+                    surf.specularTint = mat.specularTint;
+
+                    if (!trans) {                                   // :1148-1160 (no cosTheta gate here)
+                        float area, lightTriangleCount;
+                        V3 p = sampleLightPoint(sc, seed, area, lightTriangleCount);
+                        if (area > 0.0f) {
+                            V3 so = info.point + N * 0.001f;
+                            V3 toLight = p - so;
+                            V3 sdir = normalize(toLight);
+                            float distToLight = length(p - so);
+                            float cosTheta = fmax_(dot(N, sdir), 0.0f);
+                            float pdf = 1.0f / area / (float)sc.lightSourcesCount / lightTriangleCount;
+                            V3 Hd = normalize(V + sdir);
+                            float NoLd = clamp_(dot(N, sdir), 0.0f, 1.0f);
+                            float NoHd = clamp_(dot(N, Hd), 0.0f, 1.0f);
+                            float VoHd = clamp_(dot(V, Hd), 0.0f, 1.0f);
+                            float LoVd = clamp_(dot(sdir, V), 0.0f, 1.0f);
+                            float pSurf = 1.0f - lp.transmission;
+                            pSurf = (pSurf < 1e-8f) ? 0.0f : pSurf;
+                            float norm = (pSurf > 0.0f) ? 1.0f / pSurf : 1.0f;
+                            float pdfBrdfLd = lp.diffuse * (NoLd * kInvPi) + lp.specular * specularPdfSpectral(NoHd, VoHd, roughness) +
+                                              lp.subsurface * (NoLd * kInvPi);
+                            pdfBrdfLd *= norm;
+                            float brdfDirect = lp.diffuse * evalDiffuseSpectral(surf, NoLd, NoV, VoHd) +
+                                               lp.specular * evalSpecularSpectral(surf, NoV, NoLd, NoHd, VoHd) +
+                                               lp.subsurface * evalSubsurfaceSpectral(surf, NoLd, NoV, LoVd);
+                            RayRec sr;
+                            sr.ox = so.x; sr.oy = so.y; sr.oz = so.z; sr.pad0 = 0.0f;
+                            sr.dx = sdir.x; sr.dy = sdir.y; sr.dz = sdir.z; sr.pad1 = 0.0f;
+                            pb.rays[bt.P + path] = sr;
+                            pb.neeA[path] = make_float4(brdfDirect, cosTheta, pdf, dot(toLight, toLight));
+                            pb.neeB[path] = make_float4(pdfBrdfLd, distToLight, throughput, lambda);
+                            wantShadow = true;
+                        }
+                    }
+
+                    const V3 no = info.point + L * 0.001f;          // :1205
+                    bool alive = true;
+                    if (trans) {
+                        if (!info.front_face) {
+                            float al = fmax_(surf.albedo, kMinDenominator);
+                            float absorption = -log_(al);
+                            throughput *= exp_(-absorption * info.t);
+                        }
+                        prevBrdfPdf = 1.0f;
+                    } else if (NoL < kMinDenominator) {
+                        alive = false;
+                    } else {
+                        float brdfSpec = evalSpecularSpectral(surf, NoV, NoL, NoH, VoH);
+                        float brdfDiff = evalDiffuseSpectral(surf, NoL, NoV, VoH);
+                        float brdfSss = evalSubsurfaceSpectral(surf, NoL, NoV, LoV);
+                        float pSurf = 1.0f - lp.transmission;
+                        pSurf = (pSurf < 1e-8f) ? 0.0f : pSurf;
+                        float norm = (pSurf > 0.0f) ? 1.0f / pSurf : 1.0f;
+                        float pdfSss = NoL * kInvPi * lp.subsurface * norm;
+                        float pdfSpec = specularPdfSpectral(NoH, VoH, roughness) * lp.specular * norm;
+                        float pdfDiff = (NoL * kInvPi) * lp.diffuse * norm;
+                        float pdfUsed = pdfSss * sss + pdfSpec * spec + pdfDiff * diff;
+                        prevBrdfPdf = pdfUsed;
+                        float brdfTotal = (brdfSpec * spec + brdfDiff * diff + brdfSss * sss);
+                        float contribution = (brdfTotal * NoL) / fmax_(pdfUsed, kMinDenominator);
+                        throughput *= contribution;
+                        float rr = fmin_(throughput, 0.95f);
+                        if (rand_float(seed) > rr) alive = false;
+                        else throughput /= rr;
+                    }
+
+                    if (alive && !lastBounce) {
+                        RayRec nr;
+                        nr.ox = no.x; nr.oy = no.y; nr.oz = no.z; nr.pad0 = 0.0f;
+                        nr.dx = L.x; nr.dy = L.y; nr.dz = L.z; nr.pad1 = 0.0f;
+                        pb.rays[path] = nr;
+                        pb.stA[path] = make_float4(throughput, prevBrdfPdf, lambda, 0.0f);
+                        sB.x = radiance;
+                        sB.w = __uint_as_float(seed);
+                        pb.stB[path] = sB;
+                        wantExt = true;
+                    }
+                }
+            }
+        }
+        wavePush(wantShadow, pb.qShadow, &next->nShadow, bt.P + path);
+        wavePush(wantExt, qOut, &next->nExt, path);
+    }
+    if (shaded) atomicAdd(&pb.counters[3], (unsigned long long)shaded);
+}
+
+// ---- k_resolve ---------------------------------------------------------------------------
+// Adds the batch's samples into the frame sum in sample order and, when a frame
+// completes, scales by 1/ssq^2 (Spectral: XYZ -> linear sRGB) and adds it to the
+// image sum (src/RayTracer.cpp:579-583, 1368-1378).  `partial` carries an
+// unfinished frame's sample sum across batches.
+template <bool SPECTRAL>
+__global__ __launch_bounds__(kBlock) void k_resolve(FrameParams fp, Batch bt, PathBuffers pb, float4 *accum, float4 *partial) {
+    const uint32_t stride = gridDim.x * kBlock;
+    for (uint32_t q = blockIdx.x * kBlock + threadIdx.x; q < fp.npt; q += stride) {
+        int x, y;
+        if (!pathPixel(fp, q, x, y)) continue;
+        const size_t px = (size_t)y * (size_t)fp.W + (size_t)x;
+        V3 c = v3s(0.0f);
+        float4 acc = accum[px];
+        bool accDirty = false;
+        for (uint32_t k = 0; k < bt.K; ++k) {
+            const uint32_t s = (bt.g0 + k) % fp.S;
+            if (s == 0u) {
+                c = v3s(0.0f);
+            } else if (k == 0u) {
+                float4 pc = partial[px];
+                c = v3(pc.x, pc.y, pc.z);
+            }
+            const uint32_t path = k * fp.npt + q;
+            const float4 sB = pb.stB[path];
+            if (SPECTRAL) {
+                const float lambda = pb.stA[path].z;
+                c = c + cieXYZ(lambda) * (sB.x / fp.wlPdf);
+            } else {
+                c = c + v3(sB.x, sB.y, sB.z);
+            }
+            if (s == fp.S - 1u) {
+                V3 col = c * (fp.rssq * fp.rssq);
+                if (SPECTRAL) {
+                    col = col / kCieYIntegral;
+                    col = xyzEToLinearSRGB(col);
+                }
+                acc.x += col.x;
+                acc.y += col.y;
+                acc.z += col.z;
+                acc.w += 1.0f;
+                accDirty = true;
+            } else if (k == bt.K - 1u) {
+                partial[px] = make_float4(c.x, c.y, c.z, 0.0f);
+            }
+        }
+        if (accDirty) accum[px] = acc;
+    }
+}
+
+}  // namespace
+
+// ============================================================================================
+// Host side
+// ============================================================================================
+
+struct rt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string hipError;
+
+    std::vector<float> host[6];     // uploaded words per slot (1..5)
+    float *dStream[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t dStreamWords[6] = {0, 0, 0, 0, 0, 0};
+    bool dirty = true;
+
+    int objectCount = 0, modelsCount = 0, lightSourcesCount = 0;
+    bool committed = false;
+    PackedNode *dNodes = nullptr;
+    PackedTri *dTris = nullptr;
+    ModelDesc *dModelDesc = nullptr;
+    std::vector<PackedTri> hTris;   // kept for id decoding in rt_trace_primary
+    SceneView view{};
+
+    int W = 0, H = 0;
+    float4 *dAccum = nullptr;       // owned unless external
+    bool accumExternal = false;
+    float4 *dPartial = nullptr;
+    uint32_t framesAccum = 0;
+
+    FrameParams fp{};
+    int type = RT_TYPE_RGB;
+    bool frameSet = false;
+
+    uint32_t maxPaths = kDefaultMaxPaths;
+    uint32_t P = 0;                 // allocated path capacity
+    PathBuffers pb{};
+    bool countersOn = false;
+    int numCUs = 256;
+
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> traceEvents, renderEvents;
+    std::vector<hipEvent_t> eventPool;
+    double traceMs = 0.0, totalMs = 0.0;
+    uint64_t traceLaunches = 0, cameraSamples = 0;
+};
+
+namespace {
+
+#define RT_HIP(call)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            ctx->hipError = std::string(#call) + ": " + hipGetErrorString(e_);               \
+            return RT_ERR_HIP;                                                               \
+        }                                                                                    \
+    } while (0)
+
+template <typename T> int devAlloc(rt_ctx *ctx, T **ptr, size_t count) {
+    if (*ptr != nullptr) {
+        RT_HIP(hipFree(*ptr));
+        *ptr = nullptr;
+    }
+    if (count == 0) count = 1;
+    RT_HIP(hipMalloc(reinterpret_cast<void **>(ptr), count * sizeof(T)));
+    return RT_OK;
+}
+
+hipEvent_t takeEvent(rt_ctx *ctx) {
+    if (!ctx->eventPool.empty()) {
+        hipEvent_t e = ctx->eventPool.back();
+        ctx->eventPool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+// Folds finished event pairs into the millisecond totals.  Caller has synchronised.
+void drainEvents(rt_ctx *ctx) {
+    auto fold = [ctx](std::vector<std::pair<hipEvent_t, hipEvent_t>> &v, double &acc) {
+        for (auto &p : v) {
+            float ms = 0.0f;
+            if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) acc += ms;
+            ctx->eventPool.push_back(p.first);
+            ctx->eventPool.push_back(p.second);
+        }
+        v.clear();
+    };
+    fold(ctx->traceEvents, ctx->traceMs);
+    fold(ctx->renderEvents, ctx->totalMs);
+}
+
+int gridFor(const rt_ctx *ctx, uint64_t items, int blocksPerCU) {
+    uint64_t want = (items + kBlock - 1) / kBlock;
+    uint64_t cap = (uint64_t)ctx->numCUs * (uint64_t)blocksPerCU;
+    if (want < 1) want = 1;
+    return (int)std::min(want, cap);
+}
+
+// Builds the traversal re-pack from the uploaded model streams and validates
+// every offset the kernels will follow.
+int repackScene(rt_ctx *ctx, std::vector<PackedNode> &nodes, std::vector<PackedTri> &tris, std::vector<ModelDesc> &descs) {
+    const std::vector<float> &info = ctx->host[RT_SLOT_MODEL_INFO];
+    const std::vector<float> &mdl = ctx->host[RT_SLOT_MODELS];
+    const std::vector<float> &mats = ctx->host[RT_SLOT_MATERIALS];
+    const std::vector<float> &tex = ctx->host[RT_SLOT_TEXTURES];
+    const std::vector<float> &obj = ctx->host[RT_SLOT_OBJECTS];
+    const int materialCount = (int)(mats.size() / kMaterialWords);
+    if (materialCount < 1) return RT_ERR_SCENE;   // material 0 must exist
+
+    // Texture references of every material must point at a complete texture.
+    for (int m = 0; m < materialCount; ++m) {
+        for (int k = 0; k < 6; ++k) {
+            int ref = f2i(mats[(size_t)m * kMaterialWords + k]);
+            if (ref == -1) continue;
+            if (ref < 0 || (size_t)ref + 5 > tex.size()) return RT_ERR_SCENE;
+            int w = f2i(tex[ref]), h = f2i(tex[ref + 1]), c = f2i(tex[ref + 2]);
+            if (w <= 0 || h <= 0 || c <= 0 || (size_t)ref + 5 + (size_t)w * h * c > tex.size()) return RT_ERR_SCENE;
+        }
+    }
+
+    // Primitive stream: objectCount well-formed records.
+    {
+        size_t at = 0;
+        for (int i = 0; i < ctx->objectCount; ++i) {
+            if (at + 2 > obj.size()) return RT_ERR_SCENE;
+            int type = f2i(obj[at]), material = f2i(obj[at + 1]);
+            if (material < 0 || material >= materialCount) return RT_ERR_SCENE;
+            at += 2;
+            at += (type == 0) ? 4 : (type == 1) ? 10 : (type == 2) ? 18 : 0;
+            if (type < 0 || type > 2 || at > obj.size()) return RT_ERR_SCENE;
+        }
+    }
+
+    if ((size_t)ctx->modelsCount * 4 > info.size()) return RT_ERR_SCENE;
+    if (ctx->lightSourcesCount < 0 || ctx->lightSourcesCount > ctx->modelsCount) return RT_ERR_SCENE;
+    descs.resize((size_t)ctx->modelsCount);
+
+    for (int m = 0; m < ctx->modelsCount; ++m) {
+        ModelDesc d{};
+        d.identifiersCount = f2i(info[(size_t)m * 4 + 0]);
+        d.lightSourcesCount = f2i(info[(size_t)m * 4 + 1]);
+        d.nodesCount = f2i(info[(size_t)m * 4 + 2]);
+        d.lightBase = f2i(info[(size_t)m * 4 + 3]);
+        if (d.identifiersCount < 0 || d.lightSourcesCount < 0 || d.nodesCount < 0 || d.lightBase < 0) return RT_ERR_SCENE;
+        if (m < ctx->lightSourcesCount && d.lightSourcesCount <= 0) return RT_ERR_SCENE;  // light models come first
+        d.nodeBase = d.lightBase + d.lightSourcesCount * kIdentWords;
+        d.identBase = d.nodeBase + d.nodesCount * kNodeWords;
+        d.vertBase = d.identBase + d.identifiersCount * kIdentWords;
+        d.triBase = (int32_t)tris.size();
+        if ((size_t)d.vertBase > mdl.size()) return RT_ERR_SCENE;
+        const int vertexCapacity = (int)((mdl.size() - (size_t)d.vertBase) / 8);
+
+        auto checkIdent = [&](int wordAt) -> bool {
+            for (int k = 0; k < 3; ++k) {
+                int vi = f2i(mdl[(size_t)wordAt + k]);
+                if (vi < 0 || vi >= vertexCapacity) return false;
+            }
+            int mat = f2i(mdl[(size_t)wordAt + 3]);
+            return mat >= 0 && mat < materialCount;
+        };
+        for (int l = 0; l < d.lightSourcesCount; ++l)
+            for (int k = 0; k < 3; ++k) {
+                int vi = f2i(mdl[(size_t)d.lightBase + (size_t)l * kIdentWords + k]);
+                if (vi < 0 || vi >= vertexCapacity) return RT_ERR_SCENE;
+            }
+
+        // Triangles in identifier (leaf) order.
+        for (int t = 0; t < d.identifiersCount; ++t) {
+            int at = d.identBase + t * kIdentWords;
+            if (!checkIdent(at)) return RT_ERR_SCENE;
+            int idx[3] = {f2i(mdl[at]), f2i(mdl[at + 1]), f2i(mdl[at + 2])};
+            int material = f2i(mdl[at + 3]);
+            bool hasTextures = mdl[at + 4] != 0.0f;
+            const float *A = &mdl[(size_t)d.vertBase + (size_t)idx[0] * 8];
+            const float *B = &mdl[(size_t)d.vertBase + (size_t)idx[1] * 8];
+            const float *C = &mdl[(size_t)d.vertBase + (size_t)idx[2] * 8];
+            PackedTri pt;
+            for (int k = 0; k < 3; ++k) {
+                pt.a[k] = A[k];
+                pt.ab[k] = B[k] - A[k];
+                pt.ac[k] = C[k] - A[k];
+            }
+            pt.material = material;
+            pt.model = m;
+            pt.ident = t;
+            if (hasTextures) {
+                int baseColor = f2i(mats[(size_t)material * kMaterialWords + 1]);
+                float alphaCut = mats[(size_t)material * kMaterialWords + 20];
+                if (baseColor != -1 && alphaCut > 0.0f) pt.model |= kTriAlphaTest;
+            }
+            tris.push_back(pt);
+        }
+
+        // Inner nodes get consecutive packed indices in original node order.
+        std::vector<int32_t> packedIndex((size_t)d.nodesCount, -1);
+        const int32_t innerBase = (int32_t)nodes.size();
+        int32_t innerCount = 0;
+        auto nodeWord = [&](int n, int w) { return mdl[(size_t)d.nodeBase + (size_t)n * kNodeWords + w]; };
+        for (int n = 0; n < d.nodesCount; ++n)
+            if (nodeWord(n, 8) == 0.0f) packedIndex[(size_t)n] = innerBase + innerCount++;
+        auto childRef = [&](int n, int32_t &ref) -> bool {
+            if (n < 0 || n >= d.nodesCount) return false;
+            if (nodeWord(n, 8) != 0.0f) {
+                int first = f2i(nodeWord(n, 6)), last = f2i(nodeWord(n, 7));
+                int count = last - first;
+                if (first < 0 || count < 0 || count > 3 || last > d.identifiersCount) return false;
+                ref = ~(int32_t)((((uint32_t)(d.triBase + first)) << 2) | (uint32_t)count);
+            } else {
+                ref = packedIndex[(size_t)n];
+            }
+            return true;
+        };
+        nodes.resize((size_t)innerBase + (size_t)innerCount);
+        for (int n = 0; n < d.nodesCount; ++n) {
+            if (nodeWord(n, 8) != 0.0f) continue;
+            int l = f2i(nodeWord(n, 6)), r = f2i(nodeWord(n, 7));
+            // Children must come after their parent (pre-order layout): rules out cycles.
+            if (l <= n || r <= n) return RT_ERR_SCENE;
+            PackedNode pn{};
+            if (!childRef(l, pn.left) || !childRef(r, pn.right)) return RT_ERR_SCENE;
+            for (int k = 0; k < 3; ++k) {
+                pn.lmin[k] = nodeWord(l, k);
+                pn.lmax[k] = nodeWord(l, 3 + k);
+                pn.rmin[k] = nodeWord(r, k);
+                pn.rmax[k] = nodeWord(r, 3 + k);
+            }
+            nodes[(size_t)packedIndex[(size_t)n]] = pn;
+        }
+        if (d.nodesCount > 0) {
+            if (!childRef(0, d.rootRef)) return RT_ERR_SCENE;
+            // Depth bound: the traversal stack holds at most depth entries.
+            std::vector<std::pair<int, int>> todo{{0, 1}};
+            int maxDepth = 0;
+            while (!todo.empty()) {
+                auto [n, depth] = todo.back();
+                todo.pop_back();
+                maxDepth = std::max(maxDepth, depth);
+                if (nodeWord(n, 8) != 0.0f) continue;
+                todo.push_back({f2i(nodeWord(n, 6)), depth + 1});
+                todo.push_back({f2i(nodeWord(n, 7)), depth + 1});
+            }
+            if (maxDepth > kStackDepth) return RT_ERR_SCENE;
+        }
+        descs[(size_t)m] = d;
+    }
+    if (tris.size() > (size_t)kIndexMask) return RT_ERR_SCENE;
+    return RT_OK;
+}
+
+int ensurePathBuffers(rt_ctx *ctx) {
+    const uint32_t npt = ctx->fp.npt;
+    uint32_t want = std::max(npt, (ctx->maxPaths / std::max(npt, 1u)) * npt);
+    if (want == ctx->P && ctx->pb.rays != nullptr) return RT_OK;
+    int rc;
+    if ((rc = devAlloc(ctx, &ctx->pb.rays, (size_t)want * 2)) != RT_OK) return rc;
+    if ((rc = devAlloc(ctx, &ctx->pb.hits, (size_t)want * 2)) != RT_OK) return rc;
+    if ((rc = devAlloc(ctx, &ctx->pb.stA, want)) != RT_OK) return rc;
+    if ((rc = devAlloc(ctx, &ctx->pb.stB, want)) != RT_OK) return rc;
+    if ((rc = devAlloc(ctx, &ctx->pb.neeA, want)) != RT_OK) return rc;
+    if ((rc = devAlloc(ctx, &ctx->pb.neeB, want)) != RT_OK) return rc;
+    if ((rc = devAlloc(ctx, &ctx->pb.neeC, want)) != RT_OK) return rc;
+    if ((rc = devAlloc(ctx, &ctx->pb.qExt[0], want)) != RT_OK) return rc;
+    if ((rc = devAlloc(ctx, &ctx->pb.qExt[1], want)) != RT_OK) return rc;
+    if ((rc = devAlloc(ctx, &ctx->pb.qShadow, want)) != RT_OK) return rc;
+    if (ctx->pb.stages == nullptr) {
+        if ((rc = devAlloc(ctx, &ctx->pb.stages, (size_t)kMaxBounces + 2)) != RT_OK) return rc;
+    }
+    if (ctx->pb.counters == nullptr) {
+        if ((rc = devAlloc(ctx, &ctx->pb.counters, 8)) != RT_OK) return rc;
+        RT_HIP(hipMemsetAsync(ctx->pb.counters, 0, 8 * sizeof(unsigned long long), ctx->stream));
+    }
+    ctx->P = want;
+    return RT_OK;
+}
+
+void launchTrace(rt_ctx *ctx, const uint32_t *qExt, int stage) {
+    hipEvent_t e0 = takeEvent(ctx), e1 = takeEvent(ctx);
+    // 20 waves per CU: the LDS stacks (32 KiB per 256-thread block) admit 5 blocks.
+    const int grid = ctx->numCUs * 5;
+    if (e0) hipEventRecord(e0, ctx->stream);
+    if (ctx->countersOn) hipLaunchKernelGGL(k_trace<true>, dim3(grid), dim3(kBlock), 0, ctx->stream, ctx->view, ctx->pb, qExt, stage);
+    else hipLaunchKernelGGL(k_trace<false>, dim3(grid), dim3(kBlock), 0, ctx->stream, ctx->view, ctx->pb, qExt, stage);
+    if (e1) hipEventRecord(e1, ctx->stream);
+    if (e0 && e1) ctx->traceEvents.push_back({e0, e1});
+    ctx->traceLaunches++;
+}
+
+// Queues every kernel of one batch.
+int runBatch(rt_ctx *ctx, const Batch &bt) {
+    const FrameParams &fp = ctx->fp;
+    const bool spectral = ctx->type == RT_TYPE_SPECTRAL;
+    RT_HIP(hipMemsetAsync(ctx->pb.stages, 0, sizeof(Stage) * ((size_t)fp.bounces + 2), ctx->stream));
+
+    const uint64_t paths = (uint64_t)bt.K * fp.npt;
+    const int gGen = gridFor(ctx, paths, 16), gShade = gridFor(ctx, paths, 8);
+    if (spectral) hipLaunchKernelGGL(k_generate<true>, dim3(gGen), dim3(kBlock), 0, ctx->stream, fp, bt, ctx->pb);
+    else hipLaunchKernelGGL(k_generate<false>, dim3(gGen), dim3(kBlock), 0, ctx->stream, fp, bt, ctx->pb);
+
+    for (int b = 0; b <= fp.bounces; ++b) {
+        launchTrace(ctx, ctx->pb.qExt[b & 1], b);
+        if (b > 0) {
+            if (spectral) hipLaunchKernelGGL(k_connect<true>, dim3(gShade), dim3(kBlock), 0, ctx->stream, ctx->view, bt, ctx->pb, b);
+            else hipLaunchKernelGGL(k_connect<false>, dim3(gShade), dim3(kBlock), 0, ctx->stream, ctx->view, bt, ctx->pb, b);
+        }
+        if (spectral) hipLaunchKernelGGL(k_shade_spectral, dim3(gShade), dim3(kBlock), 0, ctx->stream, ctx->view, fp, bt, ctx->pb, b);
+        else hipLaunchKernelGGL(k_shade_rgb, dim3(gShade), dim3(kBlock), 0, ctx->stream, ctx->view, fp, bt, ctx->pb, b);
+    }
+    const int last = fp.bounces + 1;
+    launchTrace(ctx, nullptr, last);
+    if (spectral) hipLaunchKernelGGL(k_connect<true>, dim3(gShade), dim3(kBlock), 0, ctx->stream, ctx->view, bt, ctx->pb, last);
+    else hipLaunchKernelGGL(k_connect<false>, dim3(gShade), dim3(kBlock), 0, ctx->stream, ctx->view, bt, ctx->pb, last);
+
+    const int gRes = gridFor(ctx, fp.npt, 16);
+    if (spectral) hipLaunchKernelGGL(k_resolve<true>, dim3(gRes), dim3(kBlock), 0, ctx->stream, fp, bt, ctx->pb, ctx->dAccum, ctx->dPartial);
+    else hipLaunchKernelGGL(k_resolve<false>, dim3(gRes), dim3(kBlock), 0, ctx->stream, fp, bt, ctx->pb, ctx->dAccum, ctx->dPartial);
+    RT_HIP(hipGetLastError());
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rt_create(rt_ctx **out, int device) {
+    if (out == nullptr) return RT_ERR_INVALID;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return RT_ERR_NO_DEVICE;
+    if (device < 0 || device >= count) return RT_ERR_INVALID;
+    rt_ctx *ctx = new (std::nothrow) rt_ctx();
+    if (ctx == nullptr) return RT_ERR_NOMEM;
+    ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&ctx->stream) != hipSuccess) {
+        delete ctx;
+        return RT_ERR_HIP;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ctx->numCUs = prop.multiProcessorCount;
+    if (const char *env = std::getenv("RT_MAX_PATHS")) {
+        long v = std::atol(env);
+        if (v > 0) ctx->maxPaths = (uint32_t)std::min<long>(v, 1l << 30);
+    }
+    *out = ctx;
+    return RT_OK;
+}
+
+void rt_destroy(rt_ctx *ctx) {
+    if (ctx == nullptr) return;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    for (float *p : ctx->dStream) if (p) hipFree(p);
+    void *owned[] = {ctx->dNodes, ctx->dTris, ctx->dModelDesc, ctx->accumExternal ? nullptr : (void *)ctx->dAccum, ctx->dPartial,
+                     ctx->pb.rays, ctx->pb.hits, ctx->pb.stA, ctx->pb.stB, ctx->pb.neeA, ctx->pb.neeB, ctx->pb.neeC,
+                     ctx->pb.qExt[0], ctx->pb.qExt[1], ctx->pb.qShadow, ctx->pb.stages, ctx->pb.counters};
+    for (void *p : owned) if (p) hipFree(p);
+    drainEvents(ctx);
+    for (hipEvent_t e : ctx->eventPool) hipEventDestroy(e);
+    hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int rt_upload(rt_ctx *ctx, int slot, const void *data, size_t bytes) {
+    if (ctx == nullptr || slot < 1 || slot > 5 || (data == nullptr && bytes != 0) || (bytes % 4) != 0) return RT_ERR_INVALID;
+    const float *w = static_cast<const float *>(data);
+    ctx->host[slot].assign(w, w + bytes / 4);
+    ctx->dirty = true;
+    ctx->committed = false;
+    return RT_OK;
+}
+
+int rt_commit_scene(rt_ctx *ctx, int objectCount, int modelsCount, int lightSourcesCount) {
+    if (ctx == nullptr || objectCount < 0 || modelsCount < 0 || lightSourcesCount < 0) return RT_ERR_INVALID;
+    if (ctx->committed && !ctx->dirty && objectCount == ctx->objectCount && modelsCount == ctx->modelsCount &&
+        lightSourcesCount == ctx->lightSourcesCount)
+        return RT_OK;
+    RT_HIP(hipSetDevice(ctx->device));
+    RT_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->objectCount = objectCount;
+    ctx->modelsCount = modelsCount;
+    ctx->lightSourcesCount = lightSourcesCount;
+
+    std::vector<PackedNode> nodes;
+    std::vector<PackedTri> tris;
+    std::vector<ModelDesc> descs;
+    int rc = repackScene(ctx, nodes, tris, descs);
+    if (rc != RT_OK) return rc;
+
+    // Raw streams, each padded with 8 zero words so the one-past-the-end reads the
+    // reference's texel fetches can make (4th channel of the last RGB texel) stay in bounds.
+    for (int s = 1; s <= 5; ++s) {
+        std::vector<float> padded(ctx->host[s]);
+        padded.resize(padded.size() + 8, 0.0f);
+        if ((rc = devAlloc(ctx, &ctx->dStream[s], padded.size())) != RT_OK) return rc;
+        RT_HIP(hipMemcpy(ctx->dStream[s], padded.data(), padded.size() * sizeof(float), hipMemcpyHostToDevice));
+        ctx->dStreamWords[s] = ctx->host[s].size();
+    }
+    if ((rc = devAlloc(ctx, &ctx->dNodes, nodes.size())) != RT_OK) return rc;
+    if ((rc = devAlloc(ctx, &ctx->dTris, tris.size())) != RT_OK) return rc;
+    if ((rc = devAlloc(ctx, &ctx->dModelDesc, descs.size())) != RT_OK) return rc;
+    if (!nodes.empty()) RT_HIP(hipMemcpy(ctx->dNodes, nodes.data(), nodes.size() * sizeof(PackedNode), hipMemcpyHostToDevice));
+    if (!tris.empty()) RT_HIP(hipMemcpy(ctx->dTris, tris.data(), tris.size() * sizeof(PackedTri), hipMemcpyHostToDevice));
+    if (!descs.empty()) RT_HIP(hipMemcpy(ctx->dModelDesc, descs.data(), descs.size() * sizeof(ModelDesc), hipMemcpyHostToDevice));
+    ctx->hTris.swap(tris);
+
+    SceneView &v = ctx->view;
+    v.objects = ctx->dStream[RT_SLOT_OBJECTS];
+    v.materials = ctx->dStream[RT_SLOT_MATERIALS];
+    v.modelInfo = ctx->dStream[RT_SLOT_MODEL_INFO];
+    v.models = ctx->dStream[RT_SLOT_MODELS];
+    v.textures = ctx->dStream[RT_SLOT_TEXTURES];
+    v.nodes = ctx->dNodes;
+    v.tris = ctx->dTris;
+    v.modelDesc = ctx->dModelDesc;
+    v.objectCount = objectCount;
+    v.modelsCount = modelsCount;
+    v.lightSourcesCount = lightSourcesCount;
+    ctx->dirty = false;
+    ctx->committed = true;
+    return RT_OK;
+}
+
+int rt_resize(rt_ctx *ctx, int width, int height) {
+    if (ctx == nullptr || width <= 0 || height <= 0 || (uint64_t)width * height > (1u << 28)) return RT_ERR_INVALID;
+    RT_HIP(hipSetDevice(ctx->device));
+    RT_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->W = width;
+    ctx->H = height;
+    const size_t px = (size_t)width * height;
+    int rc;
+    if (ctx->accumExternal) {
+        ctx->dAccum = nullptr;   // an external buffer is tied to the old size
+        ctx->accumExternal = false;
+    }
+    if ((rc = devAlloc(ctx, &ctx->dAccum, px)) != RT_OK) return rc;
+    if ((rc = devAlloc(ctx, &ctx->dPartial, px)) != RT_OK) return rc;
+    RT_HIP(hipMemsetAsync(ctx->dAccum, 0, px * sizeof(float4), ctx->stream));
+    RT_HIP(hipMemsetAsync(ctx->dPartial, 0, px * sizeof(float4), ctx->stream));
+    ctx->framesAccum = 0;
+    ctx->frameSet = false;
+    return RT_OK;
+}
+
+int rt_set_frame(rt_ctx *ctx, const rt_camera *cam, const float sky_linear[3], int type) {
+    if (ctx == nullptr || cam == nullptr || sky_linear == nullptr) return RT_ERR_INVALID;
+    if (type != RT_TYPE_RGB && type != RT_TYPE_SPECTRAL) return RT_ERR_INVALID;
+    if (ctx->W <= 0) return RT_ERR_STATE;
+    if ((int)cam->resolution[0] != ctx->W || (int)cam->resolution[1] != ctx->H) return RT_ERR_INVALID;
+    if (cam->bounces < 0 || cam->bounces > kMaxBounces || cam->rayPerPixel < 1) return RT_ERR_INVALID;
+
+    FrameParams &fp = ctx->fp;
+    fp.fov = cam->fov;
+    fp.resX = cam->resolution[0];
+    fp.resY = cam->resolution[1];
+    fp.position = v3(cam->position[0], cam->position[1], cam->position[2]);
+    fp.forward = v3(cam->forward[0], cam->forward[1], cam->forward[2]);
+    fp.right = v3(cam->right[0], cam->right[1], cam->right[2]);
+    fp.up = v3(cam->up[0], cam->up[1], cam->up[2]);
+    fp.bounces = cam->bounces;
+    fp.rayPerPixel = cam->rayPerPixel;
+    fp.sky = v3(sky_linear[0], sky_linear[1], sky_linear[2]);
+
+    // Per-launch constants of fragment main() (src/RayTracer.cpp:545-557, 570-571, 1343-1346).
+    fp.rImgX = 1.0f / fp.resX;
+    fp.rImgY = 1.0f / fp.resY;
+    const V3 lookat = fp.forward + fp.position;
+    const float viewportRatio = fp.resX * fp.rImgY;
+    fp.focalLength = length(lookat - fp.position);
+    const float viewportHeight = 2.0f * tan_(kRad * fp.fov * 0.5f) * fp.focalLength;
+    const float viewportWidth = viewportHeight * viewportRatio;
+    fp.halfWidth = viewportWidth * 0.5f;
+    fp.halfHeight = viewportHeight * 0.5f;
+    fp.ssq = (int)sqrt_((float)fp.rayPerPixel);
+    if (fp.ssq < 1) return RT_ERR_INVALID;
+    fp.rssq = 1.0f / (float)fp.ssq;
+    fp.wlDt = kWlRange / (float)fp.rayPerPixel;
+    fp.wlPdf = 1.0f / kWlRange;
+    fp.W = ctx->W;
+    fp.H = ctx->H;
+    fp.tilesX = (ctx->W + 7) / 8;
+    fp.tilesY = (ctx->H + 7) / 8;
+    fp.npt = (uint32_t)fp.tilesX * (uint32_t)fp.tilesY * 64u;
+    fp.S = (uint32_t)fp.ssq * (uint32_t)fp.ssq;
+    ctx->type = type;
+    ctx->frameSet = true;
+    return RT_OK;
+}
+
+int rt_render(rt_ctx *ctx, uint32_t first_frame, uint32_t n_frames, uint32_t frame_stride) {
+    if (ctx == nullptr || frame_stride == 0) return RT_ERR_INVALID;
+    if (!ctx->committed || !ctx->frameSet || ctx->dAccum == nullptr) return RT_ERR_STATE;
+    if (n_frames == 0) return RT_OK;
+    RT_HIP(hipSetDevice(ctx->device));
+    int rc = ensurePathBuffers(ctx);
+    if (rc != RT_OK) return rc;
+
+    hipEvent_t e0 = takeEvent(ctx), e1 = takeEvent(ctx);
+    if (e0) hipEventRecord(e0, ctx->stream);
+
+    const FrameParams &fp = ctx->fp;
+    const uint64_t totalPlanes = (uint64_t)n_frames * fp.S;
+    if (totalPlanes > 0xffffffffull) return RT_ERR_INVALID;
+    const uint32_t planesPerBatch = std::max(1u, ctx->P / fp.npt);
+    for (uint64_t g = 0; g < totalPlanes; g += planesPerBatch) {
+        Batch bt;
+        bt.g0 = (uint32_t)g;
+        bt.K = (uint32_t)std::min<uint64_t>(planesPerBatch, totalPlanes - g);
+        bt.firstFrame = first_frame;
+        bt.frameStride = frame_stride;
+        bt.P = ctx->P;
+        if ((rc = runBatch(ctx, bt)) != RT_OK) return rc;
+    }
+    if (e1) hipEventRecord(e1, ctx->stream);
+    if (e0 && e1) ctx->renderEvents.push_back({e0, e1});
+    ctx->framesAccum += n_frames;
+    ctx->cameraSamples += totalPlanes * (uint64_t)ctx->W * (uint64_t)ctx->H;
+    return RT_OK;
+}
+
+int rt_reset_accum(rt_ctx *ctx) {
+    if (ctx == nullptr) return RT_ERR_INVALID;
+    if (ctx->dAccum == nullptr) return RT_ERR_STATE;
+    RT_HIP(hipSetDevice(ctx->device));
+    RT_HIP(hipMemsetAsync(ctx->dAccum, 0, (size_t)ctx->W * ctx->H * sizeof(float4), ctx->stream));
+    ctx->framesAccum = 0;
+    return RT_OK;
+}
+
+int rt_sync(rt_ctx *ctx) {
+    if (ctx == nullptr) return RT_ERR_INVALID;
+    RT_HIP(hipSetDevice(ctx->device));
+    RT_HIP(hipStreamSynchronize(ctx->stream));
+    drainEvents(ctx);
+    return RT_OK;
+}
+
+int rt_readback(rt_ctx *ctx, float *rgba_sum, size_t floats, uint32_t *frames) {
+    if (ctx == nullptr || rgba_sum == nullptr) return RT_ERR_INVALID;
+    if (ctx->dAccum == nullptr) return RT_ERR_STATE;
+    if (floats != (size_t)ctx->W * ctx->H * 4) return RT_ERR_INVALID;
+    int rc = rt_sync(ctx);
+    if (rc != RT_OK) return rc;
+    RT_HIP(hipMemcpy(rgba_sum, ctx->dAccum, floats * sizeof(float), hipMemcpyDeviceToHost));
+    if (frames) *frames = ctx->framesAccum;
+    return RT_OK;
+}
+
+int rt_accum_device_ptr(rt_ctx *ctx, void **dev_ptr, size_t *floats) {
+    if (ctx == nullptr || dev_ptr == nullptr) return RT_ERR_INVALID;
+    if (ctx->dAccum == nullptr) return RT_ERR_STATE;
+    *dev_ptr = ctx->dAccum;
+    if (floats) *floats = (size_t)ctx->W * ctx->H * 4;
+    return RT_OK;
+}
+
+int rt_bind_accum(rt_ctx *ctx, void *dev_ptr, size_t floats) {
+    if (ctx == nullptr || dev_ptr == nullptr) return RT_ERR_INVALID;
+    if (ctx->W <= 0) return RT_ERR_STATE;
+    if (floats != (size_t)ctx->W * ctx->H * 4 || (reinterpret_cast<uintptr_t>(dev_ptr) & 15u) != 0) return RT_ERR_INVALID;
+    RT_HIP(hipSetDevice(ctx->device));
+    RT_HIP(hipStreamSynchronize(ctx->stream));
+    if (!ctx->accumExternal && ctx->dAccum != nullptr) RT_HIP(hipFree(ctx->dAccum));
+    ctx->dAccum = static_cast<float4 *>(dev_ptr);
+    ctx->accumExternal = true;
+    ctx->framesAccum = 0;
+    return RT_OK;
+}
+
+int rt_add_frames(rt_ctx *ctx, uint32_t frames) {
+    if (ctx == nullptr) return RT_ERR_INVALID;
+    ctx->framesAccum += frames;
+    return RT_OK;
+}
+
+int rt_trace_primary(rt_ctx *ctx, uint32_t frame, int32_t *model, int32_t *ident, float *t, float *u, float *v) {
+    if (ctx == nullptr || model == nullptr || ident == nullptr || t == nullptr || u == nullptr || v == nullptr) return RT_ERR_INVALID;
+    if (!ctx->committed || !ctx->frameSet) return RT_ERR_STATE;
+    RT_HIP(hipSetDevice(ctx->device));
+    int rc = ensurePathBuffers(ctx);
+    if (rc != RT_OK) return rc;
+    const FrameParams &fp = ctx->fp;
+    Batch bt;
+    bt.g0 = 0;
+    bt.K = 1;
+    bt.firstFrame = frame;
+    bt.frameStride = 1;
+    bt.P = ctx->P;
+    RT_HIP(hipMemsetAsync(ctx->pb.stages, 0, sizeof(Stage) * 2, ctx->stream));
+    const int gGen = gridFor(ctx, fp.npt, 16);
+    if (ctx->type == RT_TYPE_SPECTRAL) hipLaunchKernelGGL(k_generate<true>, dim3(gGen), dim3(kBlock), 0, ctx->stream, fp, bt, ctx->pb);
+    else hipLaunchKernelGGL(k_generate<false>, dim3(gGen), dim3(kBlock), 0, ctx->stream, fp, bt, ctx->pb);
+    launchTrace(ctx, ctx->pb.qExt[0], 0);
+    RT_HIP(hipGetLastError());
+    std::vector<HitRec> hits(fp.npt);
+    RT_HIP(hipMemcpyAsync(hits.data(), ctx->pb.hits, (size_t)fp.npt * sizeof(HitRec), hipMemcpyDeviceToHost, ctx->stream));
+    if ((rc = rt_sync(ctx)) != RT_OK) return rc;
+
+    for (uint32_t q = 0; q < fp.npt; ++q) {
+        uint32_t tile = q >> 6, l = q & 63u;
+        int x = (int)(tile % (uint32_t)fp.tilesX) * 8 + (int)(l & 7u);
+        int y = (int)(tile / (uint32_t)fp.tilesX) * 8 + (int)(l >> 3);
+        if (x >= fp.W || y >= fp.H) continue;
+        const size_t at = (size_t)y * fp.W + x;
+        const HitRec &h = hits[q];
+        t[at] = h.t;
+        u[at] = 0.0f;
+        v[at] = 0.0f;
+        if (h.id == kMiss) {
+            model[at] = -1;
+            ident[at] = -1;
+        } else if (h.id & kPrimBit) {
+            model[at] = -2;
+            ident[at] = (int32_t)(h.id & kIndexMask);
+        } else {
+            const PackedTri &pt = ctx->hTris[h.id & kIndexMask];
+            model[at] = pt.model & kTriModelMask;
+            ident[at] = pt.ident;
+            u[at] = h.u;
+            v[at] = h.v;
+        }
+    }
+    return RT_OK;
+}
+
+int rt_get_stats(rt_ctx *ctx, rt_stats *out) {
+    if (ctx == nullptr || out == nullptr) return RT_ERR_INVALID;
+    int rc = rt_sync(ctx);
+    if (rc != RT_OK) return rc;
+    unsigned long long c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (ctx->pb.counters != nullptr) RT_HIP(hipMemcpy(c, ctx->pb.counters, sizeof c, hipMemcpyDeviceToHost));
+    out->rays = c[0];
+    out->camera_samples = ctx->cameraSamples;
+    out->node_visits = c[1];
+    out->tri_tests = c[2];
+    out->shaded_hits = c[3];
+    out->trace_ms = ctx->traceMs;
+    out->total_ms = ctx->totalMs;
+    out->trace_launches = ctx->traceLaunches;
+    return RT_OK;
+}
+
+int rt_reset_stats(rt_ctx *ctx) {
+    if (ctx == nullptr) return RT_ERR_INVALID;
+    int rc = rt_sync(ctx);
+    if (rc != RT_OK) return rc;
+    if (ctx->pb.counters != nullptr) RT_HIP(hipMemset(ctx->pb.counters, 0, 8 * sizeof(unsigned long long)));
+    ctx->traceMs = ctx->totalMs = 0.0;
+    ctx->traceLaunches = 0;
+    ctx->cameraSamples = 0;
+    return RT_OK;
+}
+
+int rt_set_counters(rt_ctx *ctx, int enabled) {
+    if (ctx == nullptr) return RT_ERR_INVALID;
+    ctx->countersOn = enabled != 0;
+    return RT_OK;
+}
+
+const char *rt_strerror(int status) {
+    switch (status) {
+        case RT_OK: return "ok";
+        case RT_ERR_INVALID: return "invalid argument";
+        case RT_ERR_STATE: return "call out of order";
+        case RT_ERR_HIP: return "HIP runtime error";
+        case RT_ERR_NO_DEVICE: return "no usable GPU";
+        case RT_ERR_SCENE: return "inconsistent scene streams";
+        case RT_ERR_NOMEM: return "out of memory";
+        default: return "unknown status";
+    }
+}
+
+const char *rt_last_hip_error(rt_ctx *ctx) { return ctx ? ctx->hipError.c_str() : ""; }
+
+}  // extern "C"

@@ -1,0 +1,36 @@
+// Deterministic in-memory meshes standing in for the reference's .glb assets
+// (res/models.7z is not available).  No reference counterpart; every generator
+// produces the MeshData a glTF load would: light triangles first, per-vertex
+// normals/uvs, model-local material and texture indices.
+#pragma once
+#include "MeshData.h"
+
+namespace procedural {
+
+// Cornell box [pos, pos+boxLen]^3 as triangles: ceiling lamp (emissive, two
+// triangles, the model's light set), red left wall, green right wall, white
+// floor/ceiling/back, optional front.  Flat walls carry zero vertex normals so
+// the geometric normal is used.  Colours as RaySceneBuilder::BuildCornellBox.
+MeshData CornellBox(glm::vec3 pos, float boxLen, float lightLen, float emission, bool front = false,
+                    glm::vec3 wallAlbedo = glm::vec3(1.0f));
+
+// Closed tube around a (2,3) torus knot with a seeded radial displacement:
+// nu x nv quads = 2*nu*nv triangles, nu*nv vertices, smooth vertex normals.
+// nu=2048, nv=213 gives 872,448 triangles / 436,224 vertices ("dragon class").
+MeshData KnotTube(int nu, int nv, glm::vec3 center, float scale, u32 seed, const Material &material);
+
+// Right triangular prism (8 triangles), axis along z, for the dispersion scene.
+MeshData Prism(glm::vec3 center, float side, float depth, const Material &material);
+
+// Axis-aligned emissive rectangle (two triangles) as a light-only model.
+MeshData LightPanel(glm::vec3 q, glm::vec3 u, glm::vec3 v, glm::vec3 colour, float strength);
+
+// Checker/gradient RGBA texture whose texels are k/255.0f like an 8-bit image.
+MeshData::Texture CheckerTexture(int width, int height, int channels, u32 seed, int wrapS = 10497, int wrapT = 10497);
+
+// Textured room: walls/floor with base-colour, normal, metallic-roughness,
+// emissive and occlusion maps plus an alpha-cut foliage card; exercises every
+// texture branch of the material resolver.
+MeshData TexturedRoom(glm::vec3 pos, float boxLen, int texSize, u32 seed);
+
+}  // namespace procedural
