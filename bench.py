@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mrays/s of the path-traced hot path on MI355X.
+
+Workload (BASELINE.json configs[1]): dragon-class diffuse mesh (procedural
+knot tube, 872,448 triangles) inside a Cornell box, 1920x1080, 64 samples per
+pixel (64 progressive frames x 1 sample), primary + 4 bounces, RGB integrator
+with NEE + MIS.  One *step* = those 64 spp over the whole image on every GPU.
+
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL).  The scene
+is replicated; rank r renders frames r+1, r+1+N, ... (sample-split, weak
+scaling: 64 spp per GPU per step) into its own fp32 sum buffer, and the buffers
+are summed onto rank 0 with one RCCL reduce per step inside the timed region.
+
+Prints ONE JSON line on rank 0.
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp", type=int, default=64)
+    ap.add_argument("--bounces", type=int, default=4)
+    ap.add_argument("--nu", type=int, default=2048)
+    ap.add_argument("--nv", type=int, default=213)
+    ap.add_argument("--scene", default="cornell_knot")
+    ap.add_argument("--spectral", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    from raytracer_amd import capi
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP backend has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    distributed = world > 1
+    if distributed:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    rtype = capi.RT_TYPE_SPECTRAL if args.spectral else capi.RT_TYPE_RGB
+    t_build = time.time()
+    scene = capi.Scene(args.scene, nu=args.nu, nv=args.nv)
+    t_build = time.time() - t_build
+    cam = capi.make_camera(width=args.width, height=args.height, bounces=args.bounces, ray_per_pixel=1)
+
+    be = capi.Backend(local_rank)
+    be.upload_scene(scene)
+    be.resize(args.width, args.height)
+    # The sum buffer is a torch tensor so RCCL can reduce it in place.
+    accum = torch.zeros(args.height, args.width, 4, dtype=torch.float32, device=f"cuda:{local_rank}")
+    be.bind_accum(accum.data_ptr(), accum.numel())
+    be.set_frame(cam, scene.sky, rtype)
+
+    def step(k):
+        # Frames of this step for this rank: sample-split over ranks, fresh frames every step.
+        first = 1 + k * args.spp * world + rank
+        be.render(first_frame=first, n_frames=args.spp, stride=world)
+        be.sync()
+        if distributed:
+            dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # Per-ray visit counts of this workload (one counted frame), for the algorithmic byte model.
+    be.set_counters(True)
+    be.reset_stats()
+    be.render(first_frame=1, n_frames=1, stride=1)
+    cst = be.stats()
+    be.set_counters(False)
+    nodes_per_ray = cst["node_visits"] / max(cst["rays"], 1)
+    tris_per_ray = cst["tri_tests"] / max(cst["rays"], 1)
+    hits_per_ray = cst["shaded_hits"] / max(cst["rays"], 1)
+    be.reset_accum()
+    accum.zero_()
+
+    for k in range(args.warmup):
+        step(-1 - k if False else k)
+    be.reset_accum()
+    accum.zero_()
+    be.reset_stats()
+
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(args.warmup + k)
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    st = be.stats()
+    local = torch.tensor([elapsed, float(st["rays"]), float(st["camera_samples"]), st["trace_ms"], float(st["trace_launches"])],
+                         dtype=torch.float64, device=f"cuda:{local_rank}")
+    if distributed:
+        tmax = local[:1].clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        sums = local[1:3].clone()
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+        elapsed = float(tmax[0])
+        total_rays, total_samples = float(sums[0]), float(sums[1])
+    else:
+        total_rays, total_samples = float(st["rays"]), float(st["camera_samples"])
+
+    if rank == 0:
+        mrays = total_rays / elapsed / 1e6
+        pixels = args.width * args.height
+        spp_per_s = total_samples / pixels / elapsed
+        # Algorithmic bytes per ray on the packed layout: 64 B per inner node
+        # opened, 48 B per triangle tested, 160 B of ray/hit/state queue traffic.
+        b_ray = 64.0 * nodes_per_ray + 48.0 * tris_per_ray + 160.0
+        trace_s = st["trace_ms"] / 1e3
+        launches = max(st["trace_launches"], 1)
+        achieved = st["rays"] * b_ray / max(trace_s, 1e-12) / 1e9
+        out = {
+            "metric": "Mrays/s",
+            "value": round(mrays, 3),
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.scene} (procedural dragon-class mesh, {2 * args.nu * args.nv} triangles) in Cornell box, "
+                            f"{args.width}x{args.height}, {args.spp} spp per GPU per step, primary+{args.bounces} bounces, "
+                            f"{'Spectral' if args.spectral else 'RGB'} NEE+MIS",
+                "sharding": "sample-split frames, scene replicated, RCCL sum-reduce of the fp32 accumulation buffer" if distributed else "single GPU",
+                "rays_per_camera_sample": round(total_rays / max(total_samples, 1), 4),
+            },
+            "spp_per_s": round(spp_per_s, 3),
+            "camera_samples_per_s": round(total_samples / elapsed, 1),
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "k_trace",
+                "achieved": round(achieved, 2),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5),
+                "traffic": None,
+                "bytes_per_ray": round(b_ray, 1),
+                "nodes_per_ray": round(nodes_per_ray, 3),
+                "tris_per_ray": round(tris_per_ray, 3),
+                "shaded_hits_per_ray": round(hits_per_ray, 4),
+                "avg_launch_ms": round(st["trace_ms"] / launches, 4),
+                "launches": int(launches),
+                "trace_fraction_of_step": round(st["trace_ms"] / max(st["total_ms"], 1e-9), 4),
+                "trace_only_mrays_per_s": round(st["rays"] / max(trace_s, 1e-12) / 1e6, 2),
+            },
+            "host_scene_build_s": round(t_build, 2),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, scene, cam, rtype)
+        print(json.dumps(out), flush=True)
+
+    be.close()
+    if distributed:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, scene, cam, rtype):
+    """The CPU checker (oracle/, a port of the reference GLSL) on a bounded sample of the same workload."""
+    from oracle_binding import OracleScene
+
+    threads = min(16, os.cpu_count() or 1)
+    orc = OracleScene(scene)
+    W, H = args.width, args.height
+    # Calibrate on a small centred strip, then size the sample for ~cpu-seconds of work.
+    rows = max(1, H // 60)
+    y0 = H // 2 - rows // 2
+    t0 = time.perf_counter()
+    _, st = orc.render(cam, rtype, 1, 1, 1, region=(0, y0, W, y0 + rows), threads=threads)
+    dt = time.perf_counter() - t0
+    rate = st["rays"] / max(dt, 1e-9)
+    want_rows = int(min(H, max(rows, rows * args.cpu_seconds / max(dt, 1e-3))))
+    y0 = H // 2 - want_rows // 2
+    t0 = time.perf_counter()
+    _, st = orc.render(cam, rtype, 1, 1, 1, region=(0, y0, W, y0 + want_rows), threads=threads)
+    dt = time.perf_counter() - t0
+    rate = st["rays"] / max(dt, 1e-9)
+    return {
+        "value": round(rate / 1e6, 4),
+        "unit": "Mrays/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"frame 1, rows {y0}..{y0 + want_rows - 1} of the {W}x{H} image (1 spp), {st['rays']} rays in {dt:.1f} s",
+        "spp_per_s": round(st["camera_samples"] / (W * H) / max(dt, 1e-9), 5),
+    }
+
+
+if __name__ == "__main__":
+    main()
