@@ -40,6 +40,9 @@ using namespace rtd;
 
 namespace {
 
+#ifndef RT_TRACE_WAVES
+#define RT_TRACE_WAVES 5             // waves per SIMD the traversal kernel is register-limited to
+#endif
 constexpr int kStackDepth = 32;      // int stack[32], src/RayScene.cpp:682
 constexpr int kBlock = 256;
 constexpr int kMaxBounces = 62;      // stages kept on the device
@@ -67,12 +70,25 @@ struct Batch {
     uint32_t P;          // capacity in paths; shadow-ray slots start at P
 };
 
-// Queue lengths and work cursors of one bounce, all device resident.
+// Every ray queue is split into kSubQueues sub-queues, each with its length and
+// its consumer cursor on a 128-byte line of its own: a single queue word would
+// take one atomic per wave from every CU and saturates at ~90 atomics/us.
+// Block b of any producer/consumer kernel owns sub-queue b % kSubQueues; the
+// persistent traversal kernel drains all of them.
+#ifndef RT_SUBQ
+#define RT_SUBQ 32
+#endif
+constexpr int kSubQueues = RT_SUBQ;
+static_assert(2 * kSubQueues <= 64, "the traversal kernel scans all sources with one wave-wide load");
+struct __attribute__((aligned(128))) SubQueue {
+    uint32_t count;      // entries appended by the producer kernel
+    uint32_t cursor;     // next entry the traversal kernel hands out
+    uint32_t pad[30];
+};
+// Queues of one bounce, all device resident.
 struct Stage {
-    uint32_t nExt;       // extension rays entering this bounce
-    uint32_t nShadow;    // shadow rays produced by the previous bounce
-    uint32_t cursor;     // persistent-kernel work cursor
-    uint32_t pad;
+    SubQueue ext[kSubQueues];      // extension rays entering this bounce
+    SubQueue shadow[kSubQueues];   // shadow rays produced by the previous bounce
 };
 
 struct PathBuffers {
@@ -81,8 +97,9 @@ struct PathBuffers {
     float4 *stA;         // [P]   RGB: throughput.rgb, prevBrdfPdf      Spectral: throughput, prevBrdfPdf, lambda, -
     float4 *stB;         // [P]   RGB: radiance.rgb, seed bits          Spectral: radiance, -, -, seed bits
     float4 *neeA, *neeB, *neeC;   // [P] pending NEE term of the current bounce
-    uint32_t *qExt[2];   // [P] each, ping-pong by bounce parity
-    uint32_t *qShadow;   // [P]
+    uint32_t *qExt[2];   // [kSubQueues * subCap] each, ping-pong by bounce parity
+    uint32_t *qShadow;   // [kSubQueues * subCap]
+    uint32_t subCap;     // capacity of one sub-queue
     Stage *stages;       // [kMaxBounces + 2]
     unsigned long long *counters;  // [8]: 0 rays, 1 nodeVisits, 2 triTests, 3 shadedHits
 };
@@ -154,7 +171,8 @@ __global__ __launch_bounds__(kBlock) void k_generate(FrameParams fp, Batch bt, P
                 }
             }
         }
-        wavePush(valid, pb.qExt[0], &pb.stages[0].nExt, p);
+        const uint32_t sub = blockIdx.x % kSubQueues;
+        wavePush(valid, pb.qExt[0] + (size_t)sub * pb.subCap, &pb.stages[0].ext[sub].count, p);
     }
 }
 
@@ -187,25 +205,57 @@ __device__ __noinline__ bool alphaCutRejects(const SceneView &sc, const PackedTr
     return sc.textures[at + 3] < alphaCut;
 }
 
-template <bool COUNT>
-__global__ __launch_bounds__(kBlock) void k_trace(SceneView sc, PathBuffers pb, const uint32_t *qExt, int stage) {
-    __shared__ int32_t stackLds[kBlock / 64][kStackDepth][64];
+// Persistent traversal kernel.  Each wave reserves 64 consecutive queue
+// entries with one atomic (a packet: for camera rays one 8x8 pixel tile) and
+// walks them to completion, model by model, then reserves the next packet.
+// Handing single rays to idle lanes was measured slower: it mixes unrelated
+// rays into one wave and costs registers.
+template <bool COUNT, int STACK>
+__global__ __launch_bounds__(kBlock, RT_TRACE_WAVES) void k_trace(SceneView sc, PathBuffers pb, int extParity, int stage) {
+    __shared__ int32_t stackLds[kBlock / 64][STACK][64];
     const uint32_t lane = laneId();
     int32_t(*stack)[64] = stackLds[threadIdx.x >> 6];
 
     Stage *st = &pb.stages[stage];
-    const uint32_t nExt = qExt ? st->nExt : 0u;
-    const uint32_t n = nExt + st->nShadow;
+    const uint32_t *qExt = extParity >= 0 ? pb.qExt[extParity] : nullptr;
+    // Work sources: ext sub-queues [0,kSubQueues) then shadow sub-queues; a wave
+    // starts at its own and moves on when one runs dry.
+    const int firstSource = qExt ? 0 : kSubQueues;
+    const int numSources = 2 * kSubQueues - firstSource;
+    const uint32_t waveId = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    int source = firstSource + (int)(waveId % (uint32_t)numSources);
     uint32_t cntNodes = 0, cntTris = 0;
 
     for (;;) {
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&st->cursor, 64u);
-        base = __builtin_amdgcn_readfirstlane(base);
-        if (base >= n) break;
+        SubQueue *sq = (source < kSubQueues) ? &st->ext[source] : &st->shadow[source - kSubQueues];
+        const uint32_t n = sq->count;
+        uint32_t base = n;
+        if (n != 0u) {
+            if (lane == 0) base = atomicAdd(&sq->cursor, 64u);
+            base = __builtin_amdgcn_readfirstlane(base);
+        }
+        if (base >= n) {
+            // This source is drained.  One vector load looks at every source at once
+            // (lane l reads source l); move to one that still has unclaimed entries,
+            // spreading waves over them, or stop when none is left.
+            bool has = false;
+            if ((int)lane >= firstSource && (int)lane < 2 * kSubQueues) {
+                SubQueue *o = ((int)lane < kSubQueues) ? &st->ext[lane] : &st->shadow[lane - kSubQueues];
+                has = __hip_atomic_load(&o->cursor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < o->count;
+            }
+            const unsigned long long live = __ballot(has);
+            if (live == 0ull) break;
+            int pick = (int)(waveId % (uint32_t)__popcll(live));
+            unsigned long long m = live;
+            while (pick-- > 0) m &= m - 1ull;
+            source = __ffsll((long long)m) - 1;
+            continue;
+        }
         const uint32_t i = base + lane;
-        if (i < n) {            // tail lanes idle until the wave's rays are done
-        const uint32_t slot = (i < nExt) ? qExt[i] : pb.qShadow[i - nExt];
+        if (i < n) {            // tail lanes idle until the packet is done
+        const uint32_t *q = (source < kSubQueues) ? qExt + (size_t)source * pb.subCap
+                                                    : pb.qShadow + (size_t)(source - kSubQueues) * pb.subCap;
+        const uint32_t slot = q[i];
         const float4 *rp = reinterpret_cast<const float4 *>(&pb.rays[slot]);
         const float4 r0 = rp[0], r1 = rp[1];
         const V3 ro = v3(r0.x, r0.y, r0.z), rd = v3(r1.x, r1.y, r1.z);
@@ -306,14 +356,14 @@ __global__ __launch_bounds__(kBlock) void k_trace(SceneView sc, PathBuffers pb, 
                     // The child pushed last is popped first: left when dL < dR, else right.
                     if (dL < dR) {
                         if (pushL) {
-                            if (pushR) { if (sp < kStackDepth) stack[sp++][lane] = right; }
+                            if (pushR) { if (sp < STACK) stack[sp++][lane] = right; }
                             ref = left;
                             continue;
                         }
                         if (pushR) { ref = right; continue; }
                     } else {
                         if (pushR) {
-                            if (pushL) { if (sp < kStackDepth) stack[sp++][lane] = left; }
+                            if (pushL) { if (sp < STACK) stack[sp++][lane] = left; }
                             ref = right;
                             continue;
                         }
@@ -370,14 +420,30 @@ __global__ __launch_bounds__(kBlock) void k_trace(SceneView sc, PathBuffers pb, 
         }
     }
 
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&pb.counters[0], (unsigned long long)n);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        unsigned long long total = 0;
+        for (int q = 0; q < kSubQueues; ++q) total += (qExt ? st->ext[q].count : 0u) + st->shadow[q].count;
+        atomicAdd(&pb.counters[0], total);
+    }
     if (COUNT) {
-        atomicAdd(&pb.counters[1], (unsigned long long)cntNodes);
-        atomicAdd(&pb.counters[2], (unsigned long long)cntTris);
+        for (int off = 32; off > 0; off >>= 1) {
+            cntNodes += __shfl_down(cntNodes, off);
+            cntTris += __shfl_down(cntTris, off);
+        }
+        if (lane == 0) {
+            atomicAdd(&pb.counters[1], (unsigned long long)cntNodes);
+            atomicAdd(&pb.counters[2], (unsigned long long)cntTris);
+        }
     }
 }
 
 // ---- shading ---------------------------------------------------------------------------
+// Adds the per-lane counts with one atomic per wave.  All lanes must call it.
+__device__ __forceinline__ void addShadedHits(const PathBuffers &pb, uint32_t shaded) {
+    for (int off = 32; off > 0; off >>= 1) shaded += __shfl_down(shaded, off);
+    if (laneId() == 0 && shaded) atomicAdd(&pb.counters[3], (unsigned long long)shaded);
+}
+
 struct ShadowHit {
     V3 normal;       // s_info.normal (unflipped)
     bool frontFace;
@@ -413,11 +479,14 @@ __device__ __forceinline__ ShadowHit shadowHitOf(const SceneView &sc, const RayR
 // NEE connection (src/RayTracer.cpp:439-477 RGB, :1162-1200 Spectral) for the
 // shadow rays traced in `stage`; adds into the owning path's radiance.
 template <bool SPECTRAL>
-__global__ __launch_bounds__(kBlock) void k_connect(SceneView sc, Batch bt, PathBuffers pb, int stage) {
-    const uint32_t n = pb.stages[stage].nShadow;
+__global__ __launch_bounds__(kBlock) void k_connect(SceneView sc, Batch bt, PathBuffers pb, int stage, int countOn) {
+    const uint32_t sub = blockIdx.x % kSubQueues;
+    const uint32_t n = pb.stages[stage].shadow[sub].count;
+    const uint32_t *qIn = pb.qShadow + (size_t)sub * pb.subCap;
+    const uint32_t stride = (gridDim.x / kSubQueues) * kBlock;
     uint32_t shaded = 0;
-    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-        const uint32_t slot = pb.qShadow[i];
+    for (uint32_t i = (blockIdx.x / kSubQueues) * kBlock + threadIdx.x; i < n; i += stride) {
+        const uint32_t slot = qIn[i];
         const uint32_t path = slot - bt.P;
         const RayRec sr = pb.rays[slot];
         const HitRec h = pb.hits[slot];
@@ -460,20 +529,22 @@ __global__ __launch_bounds__(kBlock) void k_connect(SceneView sc, Batch bt, Path
         }
         (void)c;
     }
-    if (shaded) atomicAdd(&pb.counters[3], (unsigned long long)shaded);
+    if (countOn) addShadedHits(pb, shaded);
 }
 
 // One bounce of traceColor (src/RayTracer.cpp:333-538) for every path in the stage's queue.
-__global__ __launch_bounds__(kBlock) void k_shade_rgb(SceneView sc, FrameParams fp, Batch bt, PathBuffers pb, int stage) {
-    const uint32_t n = pb.stages[stage].nExt;
-    const uint32_t *qIn = pb.qExt[stage & 1];
-    uint32_t *qOut = pb.qExt[(stage + 1) & 1];
+__global__ __launch_bounds__(kBlock) void k_shade_rgb(SceneView sc, FrameParams fp, Batch bt, PathBuffers pb, int stage, int countOn) {
+    const uint32_t sub = blockIdx.x % kSubQueues;
+    const uint32_t n = pb.stages[stage].ext[sub].count;
+    const uint32_t *qIn = pb.qExt[stage & 1] + (size_t)sub * pb.subCap;
+    uint32_t *qOut = pb.qExt[(stage + 1) & 1] + (size_t)sub * pb.subCap;
+    uint32_t *qShadowOut = pb.qShadow + (size_t)sub * pb.subCap;
     Stage *next = &pb.stages[stage + 1];
     const bool lastBounce = stage >= fp.bounces;
-    const uint32_t stride = gridDim.x * kBlock;
+    const uint32_t stride = (gridDim.x / kSubQueues) * kBlock;
     uint32_t shaded = 0;
 
-    for (uint32_t base = blockIdx.x * kBlock + (threadIdx.x & ~63u); base < n; base += stride) {
+    for (uint32_t base = (blockIdx.x / kSubQueues) * kBlock + (threadIdx.x & ~63u); base < n; base += stride) {
         const uint32_t i = base + laneId();
         bool wantShadow = false, wantExt = false;
         uint32_t path = 0;
@@ -626,23 +697,25 @@ __global__ __launch_bounds__(kBlock) void k_shade_rgb(SceneView sc, FrameParams 
                 }
             }
         }
-        wavePush(wantShadow, pb.qShadow, &next->nShadow, bt.P + path);
-        wavePush(wantExt, qOut, &next->nExt, path);
+        wavePush(wantShadow, qShadowOut, &next->shadow[sub].count, bt.P + path);
+        wavePush(wantExt, qOut, &next->ext[sub].count, path);
     }
-    if (shaded) atomicAdd(&pb.counters[3], (unsigned long long)shaded);
+    if (countOn) addShadedHits(pb, shaded);
 }
 
 // One bounce of traceColorWavelength (src/RayTracer.cpp:1056-1252).
-__global__ __launch_bounds__(kBlock) void k_shade_spectral(SceneView sc, FrameParams fp, Batch bt, PathBuffers pb, int stage) {
-    const uint32_t n = pb.stages[stage].nExt;
-    const uint32_t *qIn = pb.qExt[stage & 1];
-    uint32_t *qOut = pb.qExt[(stage + 1) & 1];
+__global__ __launch_bounds__(kBlock) void k_shade_spectral(SceneView sc, FrameParams fp, Batch bt, PathBuffers pb, int stage, int countOn) {
+    const uint32_t sub = blockIdx.x % kSubQueues;
+    const uint32_t n = pb.stages[stage].ext[sub].count;
+    const uint32_t *qIn = pb.qExt[stage & 1] + (size_t)sub * pb.subCap;
+    uint32_t *qOut = pb.qExt[(stage + 1) & 1] + (size_t)sub * pb.subCap;
+    uint32_t *qShadowOut = pb.qShadow + (size_t)sub * pb.subCap;
     Stage *next = &pb.stages[stage + 1];
     const bool lastBounce = stage >= fp.bounces;
-    const uint32_t stride = gridDim.x * kBlock;
+    const uint32_t stride = (gridDim.x / kSubQueues) * kBlock;
     uint32_t shaded = 0;
 
-    for (uint32_t base = blockIdx.x * kBlock + (threadIdx.x & ~63u); base < n; base += stride) {
+    for (uint32_t base = (blockIdx.x / kSubQueues) * kBlock + (threadIdx.x & ~63u); base < n; base += stride) {
         const uint32_t i = base + laneId();
         bool wantShadow = false, wantExt = false;
         uint32_t path = 0;
@@ -807,10 +880,10 @@ __global__ __launch_bounds__(kBlock) void k_shade_spectral(SceneView sc, FramePa
                 }
             }
         }
-        wavePush(wantShadow, pb.qShadow, &next->nShadow, bt.P + path);
-        wavePush(wantExt, qOut, &next->nExt, path);
+        wavePush(wantShadow, qShadowOut, &next->shadow[sub].count, bt.P + path);
+        wavePush(wantExt, qOut, &next->ext[sub].count, path);
     }
-    if (shaded) atomicAdd(&pb.counters[3], (unsigned long long)shaded);
+    if (countOn) addShadedHits(pb, shaded);
 }
 
 // ---- k_resolve ---------------------------------------------------------------------------
@@ -959,8 +1032,9 @@ void drainEvents(rt_ctx *ctx) {
 int gridFor(const rt_ctx *ctx, uint64_t items, int blocksPerCU) {
     uint64_t want = (items + kBlock - 1) / kBlock;
     uint64_t cap = (uint64_t)ctx->numCUs * (uint64_t)blocksPerCU;
-    if (want < 1) want = 1;
-    return (int)std::min(want, cap);
+    want = std::min(std::max<uint64_t>(want, 1), cap);
+    // Producer/consumer kernels map block b to sub-queue b % kSubQueues.
+    return (int)((want + kSubQueues - 1) / kSubQueues * kSubQueues);
 }
 
 // Builds the traversal re-pack from the uploaded model streams and validates
@@ -1126,9 +1200,15 @@ int ensurePathBuffers(rt_ctx *ctx) {
     if ((rc = devAlloc(ctx, &ctx->pb.neeA, want)) != RT_OK) return rc;
     if ((rc = devAlloc(ctx, &ctx->pb.neeB, want)) != RT_OK) return rc;
     if ((rc = devAlloc(ctx, &ctx->pb.neeC, want)) != RT_OK) return rc;
-    if ((rc = devAlloc(ctx, &ctx->pb.qExt[0], want)) != RT_OK) return rc;
-    if ((rc = devAlloc(ctx, &ctx->pb.qExt[1], want)) != RT_OK) return rc;
-    if ((rc = devAlloc(ctx, &ctx->pb.qShadow, want)) != RT_OK) return rc;
+    // A sub-queue receives what the blocks mapped to it produce: at most its share
+    // of the paths plus one block-round of slack per block feeding it.
+    const size_t maxGrid = (size_t)ctx->numCUs * 16 + kSubQueues;
+    const size_t subCap = ((size_t)want + kSubQueues - 1) / kSubQueues + (maxGrid / kSubQueues + 1) * kBlock;
+    if (subCap > 0xffffffffull) return RT_ERR_INVALID;
+    ctx->pb.subCap = (uint32_t)subCap;
+    if ((rc = devAlloc(ctx, &ctx->pb.qExt[0], subCap * kSubQueues)) != RT_OK) return rc;
+    if ((rc = devAlloc(ctx, &ctx->pb.qExt[1], subCap * kSubQueues)) != RT_OK) return rc;
+    if ((rc = devAlloc(ctx, &ctx->pb.qShadow, subCap * kSubQueues)) != RT_OK) return rc;
     if (ctx->pb.stages == nullptr) {
         if ((rc = devAlloc(ctx, &ctx->pb.stages, (size_t)kMaxBounces + 2)) != RT_OK) return rc;
     }
@@ -1140,13 +1220,13 @@ int ensurePathBuffers(rt_ctx *ctx) {
     return RT_OK;
 }
 
-void launchTrace(rt_ctx *ctx, const uint32_t *qExt, int stage) {
+void launchTrace(rt_ctx *ctx, int extParity, int stage) {
     hipEvent_t e0 = takeEvent(ctx), e1 = takeEvent(ctx);
     // 20 waves per CU: the LDS stacks (32 KiB per 256-thread block) admit 5 blocks.
     const int grid = ctx->numCUs * 5;
     if (e0) hipEventRecord(e0, ctx->stream);
-    if (ctx->countersOn) hipLaunchKernelGGL(k_trace<true>, dim3(grid), dim3(kBlock), 0, ctx->stream, ctx->view, ctx->pb, qExt, stage);
-    else hipLaunchKernelGGL(k_trace<false>, dim3(grid), dim3(kBlock), 0, ctx->stream, ctx->view, ctx->pb, qExt, stage);
+    if (ctx->countersOn) hipLaunchKernelGGL((k_trace<true, kStackDepth>), dim3(grid), dim3(kBlock), 0, ctx->stream, ctx->view, ctx->pb, extParity, stage);
+    else hipLaunchKernelGGL((k_trace<false, kStackDepth>), dim3(grid), dim3(kBlock), 0, ctx->stream, ctx->view, ctx->pb, extParity, stage);
     if (e1) hipEventRecord(e1, ctx->stream);
     if (e0 && e1) ctx->traceEvents.push_back({e0, e1});
     ctx->traceLaunches++;
@@ -1156,6 +1236,7 @@ void launchTrace(rt_ctx *ctx, const uint32_t *qExt, int stage) {
 int runBatch(rt_ctx *ctx, const Batch &bt) {
     const FrameParams &fp = ctx->fp;
     const bool spectral = ctx->type == RT_TYPE_SPECTRAL;
+    const int cnt = ctx->countersOn ? 1 : 0;
     RT_HIP(hipMemsetAsync(ctx->pb.stages, 0, sizeof(Stage) * ((size_t)fp.bounces + 2), ctx->stream));
 
     const uint64_t paths = (uint64_t)bt.K * fp.npt;
@@ -1164,18 +1245,18 @@ int runBatch(rt_ctx *ctx, const Batch &bt) {
     else hipLaunchKernelGGL(k_generate<false>, dim3(gGen), dim3(kBlock), 0, ctx->stream, fp, bt, ctx->pb);
 
     for (int b = 0; b <= fp.bounces; ++b) {
-        launchTrace(ctx, ctx->pb.qExt[b & 1], b);
+        launchTrace(ctx, b & 1, b);
         if (b > 0) {
-            if (spectral) hipLaunchKernelGGL(k_connect<true>, dim3(gShade), dim3(kBlock), 0, ctx->stream, ctx->view, bt, ctx->pb, b);
-            else hipLaunchKernelGGL(k_connect<false>, dim3(gShade), dim3(kBlock), 0, ctx->stream, ctx->view, bt, ctx->pb, b);
+            if (spectral) hipLaunchKernelGGL(k_connect<true>, dim3(gShade), dim3(kBlock), 0, ctx->stream, ctx->view, bt, ctx->pb, b, cnt);
+            else hipLaunchKernelGGL(k_connect<false>, dim3(gShade), dim3(kBlock), 0, ctx->stream, ctx->view, bt, ctx->pb, b, cnt);
         }
-        if (spectral) hipLaunchKernelGGL(k_shade_spectral, dim3(gShade), dim3(kBlock), 0, ctx->stream, ctx->view, fp, bt, ctx->pb, b);
-        else hipLaunchKernelGGL(k_shade_rgb, dim3(gShade), dim3(kBlock), 0, ctx->stream, ctx->view, fp, bt, ctx->pb, b);
+        if (spectral) hipLaunchKernelGGL(k_shade_spectral, dim3(gShade), dim3(kBlock), 0, ctx->stream, ctx->view, fp, bt, ctx->pb, b, cnt);
+        else hipLaunchKernelGGL(k_shade_rgb, dim3(gShade), dim3(kBlock), 0, ctx->stream, ctx->view, fp, bt, ctx->pb, b, cnt);
     }
     const int last = fp.bounces + 1;
-    launchTrace(ctx, nullptr, last);
-    if (spectral) hipLaunchKernelGGL(k_connect<true>, dim3(gShade), dim3(kBlock), 0, ctx->stream, ctx->view, bt, ctx->pb, last);
-    else hipLaunchKernelGGL(k_connect<false>, dim3(gShade), dim3(kBlock), 0, ctx->stream, ctx->view, bt, ctx->pb, last);
+    launchTrace(ctx, -1, last);
+    if (spectral) hipLaunchKernelGGL(k_connect<true>, dim3(gShade), dim3(kBlock), 0, ctx->stream, ctx->view, bt, ctx->pb, last, cnt);
+    else hipLaunchKernelGGL(k_connect<false>, dim3(gShade), dim3(kBlock), 0, ctx->stream, ctx->view, bt, ctx->pb, last, cnt);
 
     const int gRes = gridFor(ctx, fp.npt, 16);
     if (spectral) hipLaunchKernelGGL(k_resolve<true>, dim3(gRes), dim3(kBlock), 0, ctx->stream, fp, bt, ctx->pb, ctx->dAccum, ctx->dPartial);
@@ -1455,7 +1536,7 @@ int rt_trace_primary(rt_ctx *ctx, uint32_t frame, int32_t *model, int32_t *ident
     const int gGen = gridFor(ctx, fp.npt, 16);
     if (ctx->type == RT_TYPE_SPECTRAL) hipLaunchKernelGGL(k_generate<true>, dim3(gGen), dim3(kBlock), 0, ctx->stream, fp, bt, ctx->pb);
     else hipLaunchKernelGGL(k_generate<false>, dim3(gGen), dim3(kBlock), 0, ctx->stream, fp, bt, ctx->pb);
-    launchTrace(ctx, ctx->pb.qExt[0], 0);
+    launchTrace(ctx, 0, 0);
     RT_HIP(hipGetLastError());
     std::vector<HitRec> hits(fp.npt);
     RT_HIP(hipMemcpyAsync(hits.data(), ctx->pb.hits, (size_t)fp.npt * sizeof(HitRec), hipMemcpyDeviceToHost, ctx->stream));
