@@ -205,218 +205,275 @@ __device__ __noinline__ bool alphaCutRejects(const SceneView &sc, const PackedTr
     return sc.textures[at + 3] < alphaCut;
 }
 
-// Persistent traversal kernel.  Each wave reserves 64 consecutive queue
-// entries with one atomic (a packet: for camera rays one 8x8 pixel tile) and
-// walks them to completion, model by model, then reserves the next packet.
-// Handing single rays to idle lanes was measured slower: it mixes unrelated
-// rays into one wave and costs registers.
+// Per-lane traversal state of the refilling variant.
+struct LaneRay {
+    V3 ro, rd, inv;
+    float closest, afterPrimitives, tModel, maxT;
+    float bestU, bestV, mU, mV;
+    uint32_t bestId, mBest, slot;
+    int32_t ref, model, sp;
+};
+
+__device__ __forceinline__ bool enterModel(const SceneView &sc, LaneRay &r, int m) {
+    for (; m < sc.modelsCount; ++m) {
+        const ModelDesc &md = sc.modelDesc[m];
+        if (md.nodesCount <= 0) continue;
+        r.model = m;
+        r.ref = md.rootRef;
+        r.sp = 0;
+        r.tModel = 1e20f;
+        r.maxT = r.closest;
+        r.mBest = kMiss;
+        r.mU = 0.0f;
+        r.mV = 0.0f;
+        return true;
+    }
+    return false;
+}
+
+// Analytic primitives, linear scan (hit(), src/RayScene.cpp:855-891); leaves the
+// closest primitive hit in the lane state.
+template <bool COUNT>
+__device__ __forceinline__ void intersectPrimitives(const SceneView &sc, LaneRay &r, uint32_t &cntTris) {
+    const V3 ro = r.ro, rd = r.rd;
+    float closest = 1e20f;
+    uint32_t bestId = kMiss;
+    float bestU = 0.0f, bestV = 0.0f;
+    int at = 0;
+    for (int pi = 0; pi < sc.objectCount; ++pi) {
+        const int type = ldi(sc.objects, at);
+        at += 2;
+        if (type == 0) {            // hitSphere, src/RayScene.cpp:441-466
+            V3 center = ld3(sc.objects, at);
+            float radius = ldw(sc.objects, at + 3);
+            at += 4;
+            V3 dir = center - ro;
+            float a = dot(rd, rd);
+            float h = dot(rd, dir);
+            float c = dot(dir, dir) - radius * radius;
+            float disc = h * h - a * c;
+            if (!(disc < 0.0f)) {
+                float sq = sqrt_(disc);
+                float t = (h - sq) / a;
+                bool ok = true;
+                if (t <= 1e-8f || t >= closest) {
+                    t = (h + sq) / a;
+                    if (t <= 1e-8f || t >= closest) ok = false;
+                }
+                if (ok) { closest = t; bestId = kPrimBit | (uint32_t)pi; bestU = 0.0f; bestV = 0.0f; }
+            }
+        } else if (type == 1) {     // hitQuad, src/RayScene.cpp:478-508 (+ cull, :870)
+            V3 qq = ld3(sc.objects, at), qu = ld3(sc.objects, at + 3), qv = ld3(sc.objects, at + 6);
+            bool cull = ldw(sc.objects, at + 9) != 0.0f;
+            at += 10;
+            V3 normal = cross(qu, qv);
+            if (!(cull && dot(rd, normal) > 0.0f)) {
+                float denom = dot(normal, rd);
+                float nn = dot(normal, normal);
+                if (!(abs_(denom) < kMinDenominator)) {
+                    float t = dot(normal, qq - ro) / denom;
+                    if (!(t < 1e-8f || t > closest || t >= closest)) {
+                        V3 rel = (ro + t * rd) - qq;
+                        float alpha = dot(normal, cross(rel, qv)) / nn;
+                        float beta = dot(normal, cross(qu, rel)) / nn;
+                        if (!(alpha < 0.0f || alpha > 1.0f || beta < 0.0f || beta > 1.0f)) {
+                            closest = t; bestId = kPrimBit | (uint32_t)pi; bestU = 0.0f; bestV = 0.0f;
+                        }
+                    }
+                }
+            }
+        } else if (type == 2) {     // top-level Triangle through hitTriangle
+            V3 A = ld3(sc.objects, at), B = ld3(sc.objects, at + 3), C = ld3(sc.objects, at + 6);
+            at += 18;
+            if (COUNT) cntTris++;
+            V3 ab = B - A, ac = C - A;
+            V3 nrm = cross(ab, ac);
+            float det = -dot(rd, nrm);
+            if (!(abs_(det) < 1e-8f)) {
+                V3 ao = ro - A;
+                V3 dao = cross(ao, rd);
+                float invDet = 1.0f / det;
+                float t = dot(ao, nrm) * invDet;
+                if (!(t < 0.0f || t > closest || t >= closest)) {
+                    float u = dot(ac, dao) * invDet;
+                    float v = -dot(ab, dao) * invDet;
+                    if (!(u < 0.0f || v < 0.0f || u + v > 1.0f)) {
+                        closest = t; bestId = kPrimBit | (uint32_t)pi; bestU = u; bestV = v;
+                    }
+                }
+            }
+        }
+    }
+    r.closest = closest;
+    r.afterPrimitives = closest;
+    r.bestId = bestId;
+    r.bestU = bestU;
+    r.bestV = bestV;
+}
+
+// Persistent traversal kernel: a wave keeps up to 64 rays in flight
+// and, whenever `refillLanes` or more lanes are idle, reserves that many queue
+// entries with one atomic and hands them to the idle lanes (refillLanes = 64
+// keeps whole 64-ray packets together, which is what coherent camera rays want;
+// incoherent rays run best around 32).  The traversal stack of each lane lives
+// in LDS ([entry][lane], conflict free).
 template <bool COUNT, int STACK>
-__global__ __launch_bounds__(kBlock, RT_TRACE_WAVES) void k_trace(SceneView sc, PathBuffers pb, int extParity, int stage) {
+__global__ __launch_bounds__(kBlock, RT_TRACE_WAVES) void k_trace(SceneView sc, PathBuffers pb, int extParity, int stage, int refillLanes, int innerShare) {
     __shared__ int32_t stackLds[kBlock / 64][STACK][64];
     const uint32_t lane = laneId();
     int32_t(*stack)[64] = stackLds[threadIdx.x >> 6];
 
     Stage *st = &pb.stages[stage];
     const uint32_t *qExt = extParity >= 0 ? pb.qExt[extParity] : nullptr;
-    // Work sources: ext sub-queues [0,kSubQueues) then shadow sub-queues; a wave
-    // starts at its own and moves on when one runs dry.
     const int firstSource = qExt ? 0 : kSubQueues;
     const int numSources = 2 * kSubQueues - firstSource;
     const uint32_t waveId = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     int source = firstSource + (int)(waveId % (uint32_t)numSources);
+    bool drained = false;    // every source has been seen empty
+
     uint32_t cntNodes = 0, cntTris = 0;
+    bool active = false;
+    LaneRay r;
+    r.slot = 0;
 
     for (;;) {
-        SubQueue *sq = (source < kSubQueues) ? &st->ext[source] : &st->shadow[source - kSubQueues];
-        const uint32_t n = sq->count;
-        uint32_t base = n;
-        if (n != 0u) {
-            if (lane == 0) base = atomicAdd(&sq->cursor, 64u);
-            base = __builtin_amdgcn_readfirstlane(base);
-        }
-        if (base >= n) {
-            // This source is drained.  One vector load looks at every source at once
-            // (lane l reads source l); move to one that still has unclaimed entries,
-            // spreading waves over them, or stop when none is left.
-            bool has = false;
-            if ((int)lane >= firstSource && (int)lane < 2 * kSubQueues) {
-                SubQueue *o = ((int)lane < kSubQueues) ? &st->ext[lane] : &st->shadow[lane - kSubQueues];
-                has = __hip_atomic_load(&o->cursor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < o->count;
+        const unsigned long long idleMask = __ballot(!active);
+        const int nIdle = __popcll(idleMask);
+        if (!drained && nIdle >= refillLanes) {
+            SubQueue *sq = (source < kSubQueues) ? &st->ext[source] : &st->shadow[source - kSubQueues];
+            const uint32_t n = sq->count;
+            const int leader = __ffsll((long long)idleMask) - 1;
+            uint32_t base = n;
+            if (n != 0u) {
+                if ((int)lane == leader) base = atomicAdd(&sq->cursor, (uint32_t)nIdle);
+                base = __shfl(base, leader);
             }
-            const unsigned long long live = __ballot(has);
-            if (live == 0ull) break;
-            int pick = (int)(waveId % (uint32_t)__popcll(live));
-            unsigned long long m = live;
-            while (pick-- > 0) m &= m - 1ull;
-            source = __ffsll((long long)m) - 1;
-            continue;
-        }
-        const uint32_t i = base + lane;
-        if (i < n) {            // tail lanes idle until the packet is done
-        const uint32_t *q = (source < kSubQueues) ? qExt + (size_t)source * pb.subCap
-                                                    : pb.qShadow + (size_t)(source - kSubQueues) * pb.subCap;
-        const uint32_t slot = q[i];
-        const float4 *rp = reinterpret_cast<const float4 *>(&pb.rays[slot]);
-        const float4 r0 = rp[0], r1 = rp[1];
-        const V3 ro = v3(r0.x, r0.y, r0.z), rd = v3(r1.x, r1.y, r1.z);
-        const V3 inv = v3(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
-
-        float closest = 1e20f;
-        uint32_t bestId = kMiss;
-        float bestU = 0.0f, bestV = 0.0f;
-
-        // Analytic primitives, linear scan (hit(), src/RayScene.cpp:855-891).
-        int at = 0;
-        for (int pi = 0; pi < sc.objectCount; ++pi) {
-            const int type = ldi(sc.objects, at);
-            at += 2;
-            if (type == 0) {            // hitSphere, src/RayScene.cpp:441-466
-                V3 center = ld3(sc.objects, at);
-                float radius = ldw(sc.objects, at + 3);
-                at += 4;
-                V3 dir = center - ro;
-                float a = dot(rd, rd);
-                float h = dot(rd, dir);
-                float c = dot(dir, dir) - radius * radius;
-                float disc = h * h - a * c;
-                if (!(disc < 0.0f)) {
-                    float sq = sqrt_(disc);
-                    float t = (h - sq) / a;
-                    bool ok = true;
-                    if (t <= 1e-8f || t >= closest) {
-                        t = (h + sq) / a;
-                        if (t <= 1e-8f || t >= closest) ok = false;
-                    }
-                    if (ok) { closest = t; bestId = kPrimBit | (uint32_t)pi; bestU = 0.0f; bestV = 0.0f; }
+            if (base >= n) {
+                bool has = false;
+                if ((int)lane >= firstSource && (int)lane < 2 * kSubQueues) {
+                    SubQueue *o = ((int)lane < kSubQueues) ? &st->ext[lane] : &st->shadow[lane - kSubQueues];
+                    has = __hip_atomic_load(&o->cursor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < o->count;
                 }
-            } else if (type == 1) {     // hitQuad, src/RayScene.cpp:478-508 (+ cull, :870)
-                V3 qq = ld3(sc.objects, at), qu = ld3(sc.objects, at + 3), qv = ld3(sc.objects, at + 6);
-                bool cull = ldw(sc.objects, at + 9) != 0.0f;
-                at += 10;
-                V3 normal = cross(qu, qv);
-                if (!(cull && dot(rd, normal) > 0.0f)) {
-                    float denom = dot(normal, rd);
-                    float nn = dot(normal, normal);
-                    if (!(abs_(denom) < kMinDenominator)) {
-                        float t = dot(normal, qq - ro) / denom;
-                        if (!(t < 1e-8f || t > closest || t >= closest)) {
-                            V3 rel = (ro + t * rd) - qq;
-                            float alpha = dot(normal, cross(rel, qv)) / nn;
-                            float beta = dot(normal, cross(qu, rel)) / nn;
-                            if (!(alpha < 0.0f || alpha > 1.0f || beta < 0.0f || beta > 1.0f)) {
-                                closest = t; bestId = kPrimBit | (uint32_t)pi; bestU = 0.0f; bestV = 0.0f;
-                            }
-                        }
-                    }
-                }
-            } else if (type == 2) {     // top-level Triangle through hitTriangle
-                V3 A = ld3(sc.objects, at), B = ld3(sc.objects, at + 3), C = ld3(sc.objects, at + 6);
-                at += 18;
-                if (COUNT) cntTris++;
-                V3 ab = B - A, ac = C - A;
-                V3 nrm = cross(ab, ac);
-                float det = -dot(rd, nrm);
-                if (!(abs_(det) < 1e-8f)) {
-                    V3 ao = ro - A;
-                    V3 dao = cross(ao, rd);
-                    float invDet = 1.0f / det;
-                    float t = dot(ao, nrm) * invDet;
-                    if (!(t < 0.0f || t > closest || t >= closest)) {
-                        float u = dot(ac, dao) * invDet;
-                        float v = -dot(ab, dao) * invDet;
-                        if (!(u < 0.0f || v < 0.0f || u + v > 1.0f)) {
-                            closest = t; bestId = kPrimBit | (uint32_t)pi; bestU = u; bestV = v;
-                        }
-                    }
-                }
-            }
-        }
-        const float afterPrimitives = closest;
-
-        // Models in info-stream order (hitModels, src/RayScene.cpp:746-760).
-        for (int m = 0; m < sc.modelsCount; ++m) {
-            const ModelDesc md = sc.modelDesc[m];
-            if (md.nodesCount <= 0) continue;
-            float tModel = 1e20f;      // hInfo.t
-            float maxT = closest;      // `max` argument
-            uint32_t mBest = kMiss;
-            float mU = 0.0f, mV = 0.0f;
-            int sp = 0;
-            int32_t ref = md.rootRef;
-
-            for (;;) {
-                if (ref >= 0) {
-                    if (COUNT) cntNodes++;
-                    const float4 *np = reinterpret_cast<const float4 *>(&sc.nodes[ref]);
-                    const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
-                    const int32_t left = __float_as_int(n0.w), right = __float_as_int(n1.w);
-                    const float dL = slabDistance(v3(n0.x, n0.y, n0.z), v3(n1.x, n1.y, n1.z), ro, inv, tModel);
-                    const float dR = slabDistance(v3(n2.x, n2.y, n2.z), v3(n3.x, n3.y, n3.z), ro, inv, tModel);
-                    const bool pushL = dL < tModel, pushR = dR < tModel;
-                    // The child pushed last is popped first: left when dL < dR, else right.
-                    if (dL < dR) {
-                        if (pushL) {
-                            if (pushR) { if (sp < STACK) stack[sp++][lane] = right; }
-                            ref = left;
-                            continue;
-                        }
-                        if (pushR) { ref = right; continue; }
-                    } else {
-                        if (pushR) {
-                            if (pushL) { if (sp < STACK) stack[sp++][lane] = left; }
-                            ref = right;
-                            continue;
-                        }
-                        if (pushL) { ref = left; continue; }
-                    }
+                const unsigned long long live = __ballot(has);
+                if (live == 0ull) {
+                    drained = true;
                 } else {
-                    const uint32_t code = ~(uint32_t)ref;
-                    const uint32_t first = code >> 2, count = code & 3u;
-                    for (uint32_t k = 0; k < count; ++k) {
-                        if (COUNT) cntTris++;
-                        const uint32_t ti = first + k;
-                        const float4 *tp = reinterpret_cast<const float4 *>(&sc.tris[ti]);
-                        const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
-                        const V3 A = v3(q0.x, q0.y, q0.z), ab = v3(q1.x, q1.y, q1.z), ac = v3(q2.x, q2.y, q2.z);
-                        const V3 nrm = cross(ab, ac);
-                        const float det = -dot(rd, nrm);
-                        if (abs_(det) < 1e-8f) continue;
-                        const V3 ao = ro - A;
-                        const V3 dao = cross(ao, rd);
-                        const float invDet = 1.0f / det;
-                        const float t = dot(ao, nrm) * invDet;
-                        if (t < 0.0f || t > maxT || t >= tModel) continue;
-                        const float u = dot(ac, dao) * invDet;
-                        const float v = -dot(ab, dao) * invDet;
-                        if (u < 0.0f || v < 0.0f || u + v > 1.0f) continue;
-                        if (__float_as_int(q1.w) & kTriAlphaTest) {
-                            if (alphaCutRejects(sc, sc.tris[ti], ro, rd, t)) continue;
-                        }
-                        tModel = t;
-                        maxT = t;
-                        mBest = ti;
-                        mU = u;
-                        mV = v;
+                    int pick = (int)(waveId % (uint32_t)__popcll(live));
+                    unsigned long long m = live;
+                    while (pick-- > 0) m &= m - 1ull;
+                    source = __ffsll((long long)m) - 1;
+                }
+                if (nIdle == 64) {
+                    if (drained) break;
+                    continue;
+                }
+            } else {
+                const uint32_t mine = base + (uint32_t)__popcll(idleMask & ((1ull << lane) - 1ull));
+                if (!active && mine < n) {
+                    const uint32_t *q = (source < kSubQueues) ? qExt + (size_t)source * pb.subCap
+                                                                : pb.qShadow + (size_t)(source - kSubQueues) * pb.subCap;
+                    r.slot = q[mine];
+                    const float4 *rp = reinterpret_cast<const float4 *>(&pb.rays[r.slot]);
+                    const float4 r0 = rp[0], r1 = rp[1];
+                    r.ro = v3(r0.x, r0.y, r0.z);
+                    r.rd = v3(r1.x, r1.y, r1.z);
+                    r.inv = v3(1.0f / r.rd.x, 1.0f / r.rd.y, 1.0f / r.rd.z);
+                    intersectPrimitives<COUNT>(sc, r, cntTris);
+                    active = enterModel(sc, r, 0);
+                    if (!active) {   // no models: the primitive result is final
+                        HitRec rec;
+                        rec.t = r.closest; rec.u = r.bestU; rec.v = r.bestV; rec.id = r.bestId;
+                        *reinterpret_cast<float4 *>(&pb.hits[r.slot]) = *reinterpret_cast<const float4 *>(&rec);
                     }
                 }
-                if (sp == 0) break;
-                ref = stack[--sp][lane];
             }
-            if (mBest != kMiss) {
-                closest = tModel;
-                bestId = mBest;
-                bestU = mU;
-                bestV = mV;
-            }
+        } else if (nIdle == 64) {
+            break;
         }
-        if (bestId != kMiss && (bestId & kPrimBit) == 0u && !(afterPrimitives > closest)) bestId |= kNoTexBit;
 
-        HitRec rec;
-        rec.t = closest;
-        rec.u = bestU;
-        rec.v = bestV;
-        rec.id = bestId;
-        *reinterpret_cast<float4 *>(&pb.hits[slot]) = *reinterpret_cast<const float4 *>(&rec);
+        // One phase per iteration, chosen for the whole wave: open inner nodes while
+        // at least `innerShare`/64 of the active lanes sit on one, otherwise test the
+        // leaves the other lanes are parked on.  Lanes of the other kind wait, so each
+        // phase runs with most lanes enabled instead of both code paths every iteration.
+        const bool onInner = active && r.ref >= 0;
+        const int nActive = 64 - __popcll(__ballot(!active));
+        const int nInner = __popcll(__ballot(onInner));
+        const bool innerPhase = nInner * 64 >= nActive * innerShare;
+        bool pop = false;
+        if (innerPhase) {
+            if (onInner) {
+                if (COUNT) cntNodes++;
+                const float4 *np = reinterpret_cast<const float4 *>(&sc.nodes[r.ref]);
+                const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+                const int32_t left = __float_as_int(n0.w), right = __float_as_int(n1.w);
+                const float dL = slabDistance(v3(n0.x, n0.y, n0.z), v3(n1.x, n1.y, n1.z), r.ro, r.inv, r.tModel);
+                const float dR = slabDistance(v3(n2.x, n2.y, n2.z), v3(n3.x, n3.y, n3.z), r.ro, r.inv, r.tModel);
+                const bool pushL = dL < r.tModel, pushR = dR < r.tModel;
+                const bool leftFirst = dL < dR;
+                const bool takeNear = leftFirst ? pushL : pushR;
+                const bool takeFar = leftFirst ? pushR : pushL;
+                const int32_t nearRef = leftFirst ? left : right;
+                const int32_t farRef = leftFirst ? right : left;
+                pop = true;
+                if (takeNear) {
+                    if (takeFar && r.sp < STACK) stack[r.sp++][lane] = farRef;
+                    r.ref = nearRef;
+                    pop = false;
+                } else if (takeFar) {
+                    r.ref = farRef;
+                    pop = false;
+                }
+            }
+        } else if (active && r.ref < 0) {
+            const uint32_t code = ~(uint32_t)r.ref;
+            const uint32_t first = code >> 2, ntri = code & 3u;
+            for (uint32_t k = 0; k < ntri; ++k) {
+                if (COUNT) cntTris++;
+                const uint32_t ti = first + k;
+                const float4 *tp = reinterpret_cast<const float4 *>(&sc.tris[ti]);
+                const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
+                const V3 A = v3(q0.x, q0.y, q0.z), ab = v3(q1.x, q1.y, q1.z), ac = v3(q2.x, q2.y, q2.z);
+                const V3 nrm = cross(ab, ac);
+                const float det = -dot(r.rd, nrm);
+                if (abs_(det) < 1e-8f) continue;
+                const V3 ao = r.ro - A;
+                const V3 dao = cross(ao, r.rd);
+                const float invDet = 1.0f / det;
+                const float t = dot(ao, nrm) * invDet;
+                if (t < 0.0f || t > r.maxT || t >= r.tModel) continue;
+                const float u = dot(ac, dao) * invDet;
+                const float v = -dot(ab, dao) * invDet;
+                if (u < 0.0f || v < 0.0f || u + v > 1.0f) continue;
+                if (__float_as_int(q1.w) & kTriAlphaTest) {
+                    if (alphaCutRejects(sc, sc.tris[ti], r.ro, r.rd, t)) continue;
+                }
+                r.tModel = t;
+                r.maxT = t;
+                r.mBest = ti;
+                r.mU = u;
+                r.mV = v;
+            }
+            pop = true;
+        }
+        if (pop) {
+            if (r.sp > 0) {
+                r.ref = stack[--r.sp][lane];
+            } else {
+                if (r.mBest != kMiss) {
+                    r.closest = r.tModel;
+                    r.bestId = r.mBest;
+                    r.bestU = r.mU;
+                    r.bestV = r.mV;
+                }
+                if (!enterModel(sc, r, r.model + 1)) {
+                    uint32_t id = r.bestId;
+                    if (id != kMiss && (id & kPrimBit) == 0u && !(r.afterPrimitives > r.closest)) id |= kNoTexBit;
+                    HitRec rec;
+                    rec.t = r.closest; rec.u = r.bestU; rec.v = r.bestV; rec.id = id;
+                    *reinterpret_cast<float4 *>(&pb.hits[r.slot]) = *reinterpret_cast<const float4 *>(&rec);
+                    active = false;
+                }
+            }
         }
     }
 
@@ -975,6 +1032,8 @@ struct rt_ctx {
     PathBuffers pb{};
     bool countersOn = false;
     int numCUs = 256;
+    int refillLanes = 32;   // idle lanes that trigger a refill for stages > 0
+    int innerShare = 48;    // inner phase runs while >= innerShare/64 of the active lanes sit on inner nodes
 
     std::vector<std::pair<hipEvent_t, hipEvent_t>> traceEvents, renderEvents;
     std::vector<hipEvent_t> eventPool;
@@ -1225,8 +1284,10 @@ void launchTrace(rt_ctx *ctx, int extParity, int stage) {
     // 20 waves per CU: the LDS stacks (32 KiB per 256-thread block) admit 5 blocks.
     const int grid = ctx->numCUs * 5;
     if (e0) hipEventRecord(e0, ctx->stream);
-    if (ctx->countersOn) hipLaunchKernelGGL((k_trace<true, kStackDepth>), dim3(grid), dim3(kBlock), 0, ctx->stream, ctx->view, ctx->pb, extParity, stage);
-    else hipLaunchKernelGGL((k_trace<false, kStackDepth>), dim3(grid), dim3(kBlock), 0, ctx->stream, ctx->view, ctx->pb, extParity, stage);
+    // Camera rays (stage 0) stay in 64-ray packets; later stages refill idle lanes.
+    const int refill = stage == 0 ? 64 : ctx->refillLanes;
+    if (ctx->countersOn) hipLaunchKernelGGL((k_trace<true, kStackDepth>), dim3(grid), dim3(kBlock), 0, ctx->stream, ctx->view, ctx->pb, extParity, stage, refill, ctx->innerShare);
+    else hipLaunchKernelGGL((k_trace<false, kStackDepth>), dim3(grid), dim3(kBlock), 0, ctx->stream, ctx->view, ctx->pb, extParity, stage, refill, ctx->innerShare);
     if (e1) hipEventRecord(e1, ctx->stream);
     if (e0 && e1) ctx->traceEvents.push_back({e0, e1});
     ctx->traceLaunches++;
@@ -1287,6 +1348,14 @@ int rt_create(rt_ctx **out, int device) {
     if (const char *env = std::getenv("RT_MAX_PATHS")) {
         long v = std::atol(env);
         if (v > 0) ctx->maxPaths = (uint32_t)std::min<long>(v, 1l << 30);
+    }
+    if (const char *env = std::getenv("RT_INNER_SHARE")) {
+        int v = std::atoi(env);
+        if (v >= 1 && v <= 64) ctx->innerShare = v;
+    }
+    if (const char *env = std::getenv("RT_REFILL_LANES")) {
+        int v = std::atoi(env);
+        if (v >= 1 && v <= 64) ctx->refillLanes = v;
     }
     *out = ctx;
     return RT_OK;
