@@ -194,25 +194,22 @@ def cpu_baseline(args, scene, cam, rtype):
     threads = min(16, os.cpu_count() or 1)
     orc = OracleScene(scene)
     W, H = args.width, args.height
-    # Calibrate on a small centred strip, then size the sample for ~cpu-seconds of work.
-    rows = max(1, H // 60)
-    y0 = H // 2 - rows // 2
+    # Calibrate on one full 1-spp frame, then size the sample (whole frames) for ~cpu-seconds of work.
     t0 = time.perf_counter()
-    _, st = orc.render(cam, rtype, 1, 1, 1, region=(0, y0, W, y0 + rows), threads=threads)
+    _, st = orc.render(cam, rtype, 1, 1, 1, threads=threads)
+    dt = time.perf_counter() - t0
+    frames = int(max(1, min(64, round(args.cpu_seconds / max(dt, 1e-3)))))
+    t0 = time.perf_counter()
+    _, st = orc.render(cam, rtype, 1, frames, 1, threads=threads)
     dt = time.perf_counter() - t0
     rate = st["rays"] / max(dt, 1e-9)
-    want_rows = int(min(H, max(rows, rows * args.cpu_seconds / max(dt, 1e-3))))
-    y0 = H // 2 - want_rows // 2
-    t0 = time.perf_counter()
-    _, st = orc.render(cam, rtype, 1, 1, 1, region=(0, y0, W, y0 + want_rows), threads=threads)
-    dt = time.perf_counter() - t0
-    rate = st["rays"] / max(dt, 1e-9)
+    y0, want_rows = 0, H
     return {
         "value": round(rate / 1e6, 4),
         "unit": "Mrays/s",
         "cores": threads,
         "kind": "port",
-        "sample": f"frame 1, rows {y0}..{y0 + want_rows - 1} of the {W}x{H} image (1 spp), {st['rays']} rays in {dt:.1f} s",
+        "sample": f"frames 1..{frames} of the {W}x{H} image ({frames} of the step's {args.spp} spp), {st['rays']} rays in {dt:.1f} s",
         "spp_per_s": round(st["camera_samples"] / (W * H) / max(dt, 1e-9), 5),
     }
 

@@ -82,7 +82,7 @@ bool buildNamedScene(RayScene &scene, const std::string &name, const SceneParams
     }
     if (name == "cornell_knot" || name == "knot_glass") {
         scene.addModel(procedural::CornellBox(kBoxPos, 2.0f, 0.7f, 17.0f));
-        scene.addModel(procedural::KnotTube(p.nu, p.nv, glm::vec3{0.0f, 0.9f, 0.1f}, 0.2f, p.seed, name == "knot_glass" ? knotGlass() : knotDiffuse()));
+        scene.addModel(procedural::KnotTube(p.nu, p.nv, glm::vec3{0.0f, 0.95f, 0.1f}, 0.25f, p.seed, name == "knot_glass" ? knotGlass() : knotDiffuse()));
         return true;
     }
     if (name == "prism") {

@@ -1,0 +1,18 @@
+"""Shared description of the committed golden fixtures (tests/golden/*.npz)."""
+import os
+
+import numpy as np
+
+HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+CASES = {
+    "cornell_quads": ("cornell_quads", {}, 48, 36, 4, 4, 2),
+    "cornell_knot": ("cornell_knot", dict(nu=96, nv=16), 48, 36, 4, 4, 2),
+    "textured_room": ("textured_room", dict(nu=48, nv=12, tex_size=32), 48, 36, 4, 4, 2),
+    "mixed": ("mixed", dict(nu=64, nv=12), 48, 36, 3, 1, 3),
+    "prism": ("prism", {}, 40, 40, 4, 4, 2),
+}
+
+
+def load(case):
+    return np.load(os.path.join(HERE, f"{case}.npz"))

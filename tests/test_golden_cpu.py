@@ -1,0 +1,53 @@
+"""CPU: the host serialisation and the checker reproduce the committed golden vectors bit for bit."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from raytracer_amd import capi
+from oracle_binding import OracleScene
+from golden_cases import CASES, load
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_streams_and_checker_match_golden(case):
+    name, kw, W, H, bounces, rpp, frames = CASES[case]
+    g = load(case)
+    scene = capi.Scene(name, **kw)
+    assert list(g["counts"]) == [scene.object_count, scene.models_count, scene.light_sources_count]
+    assert list(g["stream_words"]) == [scene.streams[s].size for s in range(1, 6)]
+    h = hashlib.sha256()
+    for slot in range(1, 6):
+        h.update(np.ascontiguousarray(scene.streams[slot]).tobytes())
+    assert h.hexdigest() == str(g["stream_sha256"]), "serialised streams changed (wire format or scene build)"
+
+    cam = capi.make_camera(width=W, height=H, bounces=bounces, ray_per_pixel=rpp)
+    orc = OracleScene(scene)
+    m, i, t, u, v, _ = orc.trace_primary(cam, frame=1)
+    for key, got in (("model", m), ("ident", i), ("t", t), ("u", u), ("v", v)):
+        assert np.array_equal(got, g[key]), key
+    rgb, st = orc.render(cam, 0, 1, frames, 1)
+    assert np.array_equal(rgb, g["rgb"])
+    assert [st[k] for k in ("rays", "node_visits", "tri_tests", "shaded_hits", "camera_samples")] == list(g["rgb_stats"])
+    spec, st2 = orc.render(cam, 1, 1, frames, 1)
+    assert np.array_equal(spec, g["spectral"], equal_nan=True)
+    assert st2["rays"] == int(g["spectral_rays"])
+
+
+def test_checker_is_thread_count_invariant():
+    scene = capi.Scene("mixed", nu=32, nv=8)
+    cam = capi.make_camera(width=32, height=24, bounces=3, ray_per_pixel=4)
+    orc = OracleScene(scene)
+    a, sa = orc.render(cam, 0, 1, 2, 1, threads=1)
+    b, sb = orc.render(cam, 0, 1, 2, 1, threads=7)
+    assert np.array_equal(a, b) and sa == sb
+
+
+def test_checker_region_equals_full_frame():
+    scene = capi.Scene("cornell_knot", nu=32, nv=8)
+    cam = capi.make_camera(width=40, height=30, bounces=3, ray_per_pixel=1)
+    orc = OracleScene(scene)
+    full, _ = orc.render(cam, 0, 2, 2, 3)
+    part, _ = orc.render(cam, 0, 2, 2, 3, region=(8, 5, 30, 21))
+    assert np.array_equal(part[5:21, 8:30], full[5:21, 8:30])
+    assert not part[:5].any() and not part[21:].any()

