@@ -40,9 +40,6 @@ using namespace rtd;
 
 namespace {
 
-#ifndef RT_TRACE_WAVES
-#define RT_TRACE_WAVES 5             // waves per SIMD the traversal kernel is register-limited to
-#endif
 constexpr int kStackDepth = 32;      // int stack[32], src/RayScene.cpp:682
 constexpr int kBlock = 256;
 constexpr int kMaxBounces = 62;      // stages kept on the device
@@ -317,8 +314,8 @@ __device__ __forceinline__ void intersectPrimitives(const SceneView &sc, LaneRay
 // keeps whole 64-ray packets together, which is what coherent camera rays want;
 // incoherent rays run best around 32).  The traversal stack of each lane lives
 // in LDS ([entry][lane], conflict free).
-template <bool COUNT, int STACK>
-__global__ __launch_bounds__(kBlock, RT_TRACE_WAVES) void k_trace(SceneView sc, PathBuffers pb, int extParity, int stage, int refillLanes, int innerShare) {
+template <bool COUNT, int STACK, bool ALPHA>
+__global__ __launch_bounds__(kBlock, (STACK <= 24 ? 6 : 5)) void k_trace(SceneView sc, PathBuffers pb, int extParity, int stage, int refillLanes, int innerShare) {
     __shared__ int32_t stackLds[kBlock / 64][STACK][64];
     const uint32_t lane = laneId();
     int32_t(*stack)[64] = stackLds[threadIdx.x >> 6];
@@ -444,7 +441,7 @@ __global__ __launch_bounds__(kBlock, RT_TRACE_WAVES) void k_trace(SceneView sc, 
                 const float u = dot(ac, dao) * invDet;
                 const float v = -dot(ab, dao) * invDet;
                 if (u < 0.0f || v < 0.0f || u + v > 1.0f) continue;
-                if (__float_as_int(q1.w) & kTriAlphaTest) {
+                if (ALPHA && (__float_as_int(q1.w) & kTriAlphaTest)) {
                     if (alphaCutRejects(sc, sc.tris[ti], r.ro, r.rd, t)) continue;
                 }
                 r.tModel = t;
@@ -1032,6 +1029,8 @@ struct rt_ctx {
     PathBuffers pb{};
     bool countersOn = false;
     int numCUs = 256;
+    int maxTreeDepth = 0;
+    bool hasAlphaTest = false;
     int refillLanes = 32;   // idle lanes that trigger a refill for stages > 0
     int innerShare = 48;    // inner phase runs while >= innerShare/64 of the active lanes sit on inner nodes
 
@@ -1131,6 +1130,8 @@ int repackScene(rt_ctx *ctx, std::vector<PackedNode> &nodes, std::vector<PackedT
         }
     }
 
+    ctx->maxTreeDepth = 0;
+    ctx->hasAlphaTest = false;
     if ((size_t)ctx->modelsCount * 4 > info.size()) return RT_ERR_SCENE;
     if (ctx->lightSourcesCount < 0 || ctx->lightSourcesCount > ctx->modelsCount) return RT_ERR_SCENE;
     descs.resize((size_t)ctx->modelsCount);
@@ -1186,7 +1187,10 @@ int repackScene(rt_ctx *ctx, std::vector<PackedNode> &nodes, std::vector<PackedT
             if (hasTextures) {
                 int baseColor = f2i(mats[(size_t)material * kMaterialWords + 1]);
                 float alphaCut = mats[(size_t)material * kMaterialWords + 20];
-                if (baseColor != -1 && alphaCut > 0.0f) pt.model |= kTriAlphaTest;
+                if (baseColor != -1 && alphaCut > 0.0f) {
+                    pt.model |= kTriAlphaTest;
+                    ctx->hasAlphaTest = true;
+                }
             }
             tris.push_back(pt);
         }
@@ -1240,6 +1244,7 @@ int repackScene(rt_ctx *ctx, std::vector<PackedNode> &nodes, std::vector<PackedT
                 todo.push_back({f2i(nodeWord(n, 7)), depth + 1});
             }
             if (maxDepth > kStackDepth) return RT_ERR_SCENE;
+            ctx->maxTreeDepth = std::max(ctx->maxTreeDepth, maxDepth);
         }
         descs[(size_t)m] = d;
     }
@@ -1281,13 +1286,19 @@ int ensurePathBuffers(rt_ctx *ctx) {
 
 void launchTrace(rt_ctx *ctx, int extParity, int stage) {
     hipEvent_t e0 = takeEvent(ctx), e1 = takeEvent(ctx);
-    // 20 waves per CU: the LDS stacks (32 KiB per 256-thread block) admit 5 blocks.
-    const int grid = ctx->numCUs * 5;
     if (e0) hipEventRecord(e0, ctx->stream);
     // Camera rays (stage 0) stay in 64-ray packets; later stages refill idle lanes.
     const int refill = stage == 0 ? 64 : ctx->refillLanes;
-    if (ctx->countersOn) hipLaunchKernelGGL((k_trace<true, kStackDepth>), dim3(grid), dim3(kBlock), 0, ctx->stream, ctx->view, ctx->pb, extParity, stage, refill, ctx->innerShare);
-    else hipLaunchKernelGGL((k_trace<false, kStackDepth>), dim3(grid), dim3(kBlock), 0, ctx->stream, ctx->view, ctx->pb, extParity, stage, refill, ctx->innerShare);
+    // Kernel variant: visit counting, LDS stack depth (24 entries let 6 blocks share a
+    // CU's LDS instead of 5), alpha-cut support only when some triangle needs it.
+    using TraceFn = void (*)(SceneView, PathBuffers, int, int, int, int);
+    static const TraceFn variants[2][2][2] = {
+        {{k_trace<false, 24, false>, k_trace<false, 24, true>}, {k_trace<false, kStackDepth, false>, k_trace<false, kStackDepth, true>}},
+        {{k_trace<true, 24, false>, k_trace<true, 24, true>}, {k_trace<true, kStackDepth, false>, k_trace<true, kStackDepth, true>}}};
+    const bool deep = ctx->maxTreeDepth > 24;
+    const TraceFn fn = variants[ctx->countersOn ? 1 : 0][deep ? 1 : 0][ctx->hasAlphaTest ? 1 : 0];
+    const int grid = ctx->numCUs * (deep ? 5 : 6);
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(kBlock), 0, ctx->stream, ctx->view, ctx->pb, extParity, stage, refill, ctx->innerShare);
     if (e1) hipEventRecord(e1, ctx->stream);
     if (e0 && e1) ctx->traceEvents.push_back({e0, e1});
     ctx->traceLaunches++;
