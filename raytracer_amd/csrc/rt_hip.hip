@@ -40,6 +40,9 @@ using namespace rtd;
 
 namespace {
 
+#ifndef RT_W20
+#define RT_W20 7
+#endif
 constexpr int kStackDepth = 32;      // int stack[32], src/RayScene.cpp:682
 constexpr int kBlock = 256;
 constexpr int kMaxBounces = 62;      // stages kept on the device
@@ -315,7 +318,7 @@ __device__ __forceinline__ void intersectPrimitives(const SceneView &sc, LaneRay
 // incoherent rays run best around 32).  The traversal stack of each lane lives
 // in LDS ([entry][lane], conflict free).
 template <bool COUNT, int STACK, bool ALPHA>
-__global__ __launch_bounds__(kBlock, (STACK <= 24 ? 6 : 5)) void k_trace(SceneView sc, PathBuffers pb, int extParity, int stage, int refillLanes, int innerShare) {
+__global__ __launch_bounds__(kBlock, (STACK <= 20 ? RT_W20 : STACK <= 24 ? 6 : 5)) void k_trace(SceneView sc, PathBuffers pb, int extParity, int stage, int refillLanes, int innerShare) {
     __shared__ int32_t stackLds[kBlock / 64][STACK][64];
     const uint32_t lane = laneId();
     int32_t(*stack)[64] = stackLds[threadIdx.x >> 6];
@@ -1292,12 +1295,12 @@ void launchTrace(rt_ctx *ctx, int extParity, int stage) {
     // Kernel variant: visit counting, LDS stack depth (24 entries let 6 blocks share a
     // CU's LDS instead of 5), alpha-cut support only when some triangle needs it.
     using TraceFn = void (*)(SceneView, PathBuffers, int, int, int, int);
-    static const TraceFn variants[2][2][2] = {
-        {{k_trace<false, 24, false>, k_trace<false, 24, true>}, {k_trace<false, kStackDepth, false>, k_trace<false, kStackDepth, true>}},
-        {{k_trace<true, 24, false>, k_trace<true, 24, true>}, {k_trace<true, kStackDepth, false>, k_trace<true, kStackDepth, true>}}};
-    const bool deep = ctx->maxTreeDepth > 24;
-    const TraceFn fn = variants[ctx->countersOn ? 1 : 0][deep ? 1 : 0][ctx->hasAlphaTest ? 1 : 0];
-    const int grid = ctx->numCUs * (deep ? 5 : 6);
+    static const TraceFn variants[2][3][2] = {
+        {{k_trace<false, 20, false>, k_trace<false, 20, true>}, {k_trace<false, 24, false>, k_trace<false, 24, true>}, {k_trace<false, kStackDepth, false>, k_trace<false, kStackDepth, true>}},
+        {{k_trace<true, 20, false>, k_trace<true, 20, true>}, {k_trace<true, 24, false>, k_trace<true, 24, true>}, {k_trace<true, kStackDepth, false>, k_trace<true, kStackDepth, true>}}};
+    const int depthClass = ctx->maxTreeDepth <= 20 ? 0 : ctx->maxTreeDepth <= 24 ? 1 : 2;
+    const TraceFn fn = variants[ctx->countersOn ? 1 : 0][depthClass][ctx->hasAlphaTest ? 1 : 0];
+    const int grid = ctx->numCUs * (depthClass == 0 ? RT_W20 : depthClass == 1 ? 6 : 5);
     hipLaunchKernelGGL(fn, dim3(grid), dim3(kBlock), 0, ctx->stream, ctx->view, ctx->pb, extParity, stage, refill, ctx->innerShare);
     if (e1) hipEventRecord(e1, ctx->stream);
     if (e0 && e1) ctx->traceEvents.push_back({e0, e1});
