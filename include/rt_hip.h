@@ -126,6 +126,19 @@ int rt_reset_stats(rt_ctx *ctx);
 /* Enables per-ray node/triangle visit counting (slower; off by default). */
 int rt_set_counters(rt_ctx *ctx, int enabled);
 
+/* Tuning switches (no reference counterpart).  None of them changes any output value.
+ *   RT_OPT_SHADOW_EARLY_OUT  RGB shadow rays stop at the first hit nearer than
+ *                            distToLight - 1e-4: such a hit already fails the reference's
+ *                            visibility test (src/RayTracer.cpp:439), so finishing the
+ *                            closest-hit search cannot change the result.  Default 1.
+ *                            With 0 every ray does the reference's full closest-hit walk
+ *                            (the visit counters then equal the reference algorithm's).
+ *   RT_OPT_REFILL_LANES      idle lanes that trigger a refill in the traversal kernel (1..64)
+ *   RT_OPT_INNER_SHARE       share (x/64) of active lanes on inner nodes that selects the
+ *                            inner-node phase (1..64) */
+enum { RT_OPT_SHADOW_EARLY_OUT = 1, RT_OPT_REFILL_LANES = 2, RT_OPT_INNER_SHARE = 3 };
+int rt_set_option(rt_ctx *ctx, int option, int value);
+
 const char *rt_strerror(int status);
 const char *rt_last_hip_error(rt_ctx *ctx);
 

@@ -642,7 +642,7 @@ static V3 computeF0(const HitInfo &info) {
     V3 f0 = v3s(0.16f * specular * specular);
     return rtm::vmix(f0, info.mat.albedo, info.mat.metallic);
 }
-static V3 fresnelSchlick3(float cosTheta, V3 F0) { return F0 + (v3s(1.0f) - F0) * rtm::pow_(1.0f - cosTheta, 5.0f); }
+static V3 fresnelSchlick3(float cosTheta, V3 F0) { return F0 + (v3s(1.0f) - F0) * rtm::pow5_(1.0f - cosTheta); }
 static float NDF_GGX(float NoH, float roughness) {
     float a = roughness * roughness;
     float a2 = a * a;
@@ -674,13 +674,13 @@ static V3 shadeDiffuse(const HitInfo &info, float NoL, float NoV, float VoH) {
     V3 F = fresnelSchlick3(VoH, F0);
     V3 kd = (v3s(1.0f) - F) * (1.0f - info.mat.metallic);
     float FD90 = 0.5f + 2.0f * info.mat.roughness * VoH * VoH;
-    float fresnelDiffuse = (1.0f + (FD90 - 1.0f) * rtm::pow_(1.0f - NoL, 5.0f)) * (1.0f + (FD90 - 1.0f) * rtm::pow_(1.0f - NoV, 5.0f));
+    float fresnelDiffuse = (1.0f + (FD90 - 1.0f) * rtm::pow5_(1.0f - NoL)) * (1.0f + (FD90 - 1.0f) * rtm::pow5_(1.0f - NoV));
     return kd * info.mat.albedo * INV_PI * fresnelDiffuse;
 }
 static float diffusePdf(float NoL) { return NoL * INV_PI; }
 static V3 shadeSubsurface(const HitInfo &info, float NoL, float NoV, float LoV) {
-    float FL = rtm::pow_(1.0f - NoL, 5.0f);
-    float FV = rtm::pow_(1.0f - NoV, 5.0f);
+    float FL = rtm::pow5_(1.0f - NoL);
+    float FV = rtm::pow5_(1.0f - NoV);
     float Fd90 = 0.5f + 2.0f * LoV * info.mat.roughness;
     float Fd = rtm::mix_(1.0f, Fd90, FL) * rtm::mix_(1.0f, Fd90, FV);
     return info.mat.albedo * Fd * INV_PI * info.mat.subsurface;
@@ -694,7 +694,7 @@ static V3 refract(V3 uv, V3 n, float etai_over_etat) {
 static float fresnelSchlickIor(float cosine, float reflectance_index) {
     float r0 = (1.0f - reflectance_index) / (1.0f + reflectance_index);
     r0 = r0 * r0;
-    return r0 + (1.0f - r0) * rtm::pow_(1.0f - cosine, 5.0f);
+    return r0 + (1.0f - r0) * rtm::pow5_(1.0f - cosine);
 }
 
 typedef V3 (*HalfVectorSampler)(V3, V3, float, uint32_t &);

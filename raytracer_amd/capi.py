@@ -14,12 +14,13 @@ _LIB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib")
 
 RT_SLOT_OBJECTS, RT_SLOT_MATERIALS, RT_SLOT_MODEL_INFO, RT_SLOT_MODELS, RT_SLOT_TEXTURES = 1, 2, 3, 4, 5
 RT_TYPE_RGB, RT_TYPE_SPECTRAL = 0, 1
+RT_OPT_SHADOW_EARLY_OUT, RT_OPT_REFILL_LANES, RT_OPT_INNER_SHARE = 1, 2, 3
 
 # Every symbol include/rt_hip.h declares.
 HIP_SYMBOLS = [
     "rt_create", "rt_destroy", "rt_upload", "rt_commit_scene", "rt_resize", "rt_set_frame", "rt_render",
     "rt_reset_accum", "rt_sync", "rt_readback", "rt_accum_device_ptr", "rt_bind_accum", "rt_add_frames",
-    "rt_trace_primary", "rt_get_stats", "rt_reset_stats", "rt_set_counters", "rt_strerror", "rt_last_hip_error",
+    "rt_trace_primary", "rt_get_stats", "rt_reset_stats", "rt_set_counters", "rt_set_option", "rt_strerror", "rt_last_hip_error",
 ]
 # Every symbol include/rt_host.h declares.
 HOST_SYMBOLS = [
@@ -90,6 +91,7 @@ hip.rt_trace_primary.argtypes = [_vp, _u32, _vp, _vp, _vp, _vp, _vp]
 hip.rt_get_stats.argtypes = [_vp, C.POINTER(RtStats)]
 hip.rt_reset_stats.argtypes = [_vp]
 hip.rt_set_counters.argtypes = [_vp, _i]
+hip.rt_set_option.argtypes = [_vp, _i, _i]
 hip.rt_strerror.argtypes = [_i]
 hip.rt_strerror.restype = C.c_char_p
 hip.rt_last_hip_error.argtypes = [_vp]
@@ -234,6 +236,9 @@ class Backend:
 
     def reset_stats(self):
         self._check(hip.rt_reset_stats(self._ctx))
+
+    def set_option(self, option, value):
+        self._check(hip.rt_set_option(self._ctx, option, int(value)))
 
     def set_counters(self, enabled):
         self._check(hip.rt_set_counters(self._ctx, 1 if enabled else 0))

@@ -83,7 +83,7 @@ template <bool SPECTRAL> RT_FN V3 sampleSpecular(V3 n, V3 v, float roughness, ui
     return (dot(n, l) > 0.0f) ? l : v3s(0.0f);
 }
 
-RT_FN float pow5(float x) { return pow_(x, 5.0f); }
+RT_FN float pow5(float x) { return pow5_(x); }
 
 // refract, src/RayTracer.cpp:280-285
 RT_FN V3 refractThrough(V3 uv, V3 n, float etaRatio) {

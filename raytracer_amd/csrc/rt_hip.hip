@@ -47,6 +47,7 @@ constexpr int kStackDepth = 32;      // int stack[32], src/RayScene.cpp:682
 constexpr int kBlock = 256;
 constexpr int kMaxBounces = 62;      // stages kept on the device
 constexpr uint32_t kDefaultMaxPaths = 8u << 20;
+constexpr float kNeverStop = -1e30f;  // RayRec::pad1 of rays that must find their closest hit
 
 // Per-frame uniforms plus values derived from them once on the host.
 struct FrameParams {
@@ -61,6 +62,7 @@ struct FrameParams {
     int32_t W, H, tilesX, tilesY;
     uint32_t npt;       // padded pixels per sample plane: tilesX*tilesY*64
     uint32_t S;         // samples per frame = ssq*ssq
+    int32_t shadowEarlyOut;   // RGB shadow rays stop at the first hit that already proves occlusion
 };
 
 struct Batch {
@@ -159,7 +161,7 @@ __global__ __launch_bounds__(kBlock) void k_generate(FrameParams fp, Batch bt, P
 
                 RayRec r;
                 r.ox = fp.position.x; r.oy = fp.position.y; r.oz = fp.position.z; r.pad0 = 0.0f;
-                r.dx = d.x; r.dy = d.y; r.dz = d.z; r.pad1 = 0.0f;
+                r.dx = d.x; r.dy = d.y; r.dz = d.z; r.pad1 = kNeverStop;
                 pb.rays[p] = r;
                 if (SPECTRAL) {
                     float lambda = (rand_float(seed) + (float)(i * fp.ssq) + (float)j) * fp.wlDt + kWlMin;
@@ -209,6 +211,7 @@ __device__ __noinline__ bool alphaCutRejects(const SceneView &sc, const PackedTr
 struct LaneRay {
     V3 ro, rd, inv;
     float closest, afterPrimitives, tModel, maxT;
+    float tStop;   // any accepted hit closer than this ends the ray at once (occluded shadow ray)
     float bestU, bestV, mU, mV;
     uint32_t bestId, mBest, slot;
     int32_t ref, model, sp;
@@ -378,9 +381,10 @@ __global__ __launch_bounds__(kBlock, (STACK <= 20 ? RT_W20 : STACK <= 24 ? 6 : 5
                     r.ro = v3(r0.x, r0.y, r0.z);
                     r.rd = v3(r1.x, r1.y, r1.z);
                     r.inv = v3(1.0f / r.rd.x, 1.0f / r.rd.y, 1.0f / r.rd.z);
+                    r.tStop = r1.w;
                     intersectPrimitives<COUNT>(sc, r, cntTris);
-                    active = enterModel(sc, r, 0);
-                    if (!active) {   // no models: the primitive result is final
+                    active = !(r.closest < r.tStop) && enterModel(sc, r, 0);
+                    if (!active) {   // no models (or already occluded): the primitive result is final
                         HitRec rec;
                         rec.t = r.closest; rec.u = r.bestU; rec.v = r.bestV; rec.id = r.bestId;
                         *reinterpret_cast<float4 *>(&pb.hits[r.slot]) = *reinterpret_cast<const float4 *>(&rec);
@@ -399,7 +403,7 @@ __global__ __launch_bounds__(kBlock, (STACK <= 20 ? RT_W20 : STACK <= 24 ? 6 : 5
         const int nActive = 64 - __popcll(__ballot(!active));
         const int nInner = __popcll(__ballot(onInner));
         const bool innerPhase = nInner * 64 >= nActive * innerShare;
-        bool pop = false;
+        bool pop = false, occluded = false;
         if (innerPhase) {
             if (onInner) {
                 if (COUNT) cntNodes++;
@@ -454,9 +458,10 @@ __global__ __launch_bounds__(kBlock, (STACK <= 20 ? RT_W20 : STACK <= 24 ? 6 : 5
                 r.mV = v;
             }
             pop = true;
+            occluded = r.tModel < r.tStop;
         }
         if (pop) {
-            if (r.sp > 0) {
+            if (r.sp > 0 && !occluded) {
                 r.ref = stack[--r.sp][lane];
             } else {
                 if (r.mBest != kMiss) {
@@ -465,7 +470,7 @@ __global__ __launch_bounds__(kBlock, (STACK <= 20 ? RT_W20 : STACK <= 24 ? 6 : 5
                     r.bestU = r.mU;
                     r.bestV = r.mV;
                 }
-                if (!enterModel(sc, r, r.model + 1)) {
+                if (occluded || !enterModel(sc, r, r.model + 1)) {
                     uint32_t id = r.bestId;
                     if (id != kMiss && (id & kPrimBit) == 0u && !(r.afterPrimitives > r.closest)) id |= kNoTexBit;
                     HitRec rec;
@@ -536,7 +541,7 @@ __device__ __forceinline__ ShadowHit shadowHitOf(const SceneView &sc, const RayR
 // NEE connection (src/RayTracer.cpp:439-477 RGB, :1162-1200 Spectral) for the
 // shadow rays traced in `stage`; adds into the owning path's radiance.
 template <bool SPECTRAL>
-__global__ __launch_bounds__(kBlock) void k_connect(SceneView sc, Batch bt, PathBuffers pb, int stage, int countOn) {
+__global__ __launch_bounds__(kBlock) void k_connect(SceneView sc, Batch bt, PathBuffers pb, int stage, int countOn, int skipOccluded) {
     const uint32_t sub = blockIdx.x % kSubQueues;
     const uint32_t n = pb.stages[stage].shadow[sub].count;
     const uint32_t *qIn = pb.qShadow + (size_t)sub * pb.subCap;
@@ -547,9 +552,11 @@ __global__ __launch_bounds__(kBlock) void k_connect(SceneView sc, Batch bt, Path
         const uint32_t path = slot - bt.P;
         const RayRec sr = pb.rays[slot];
         const HitRec h = pb.hits[slot];
+        const float4 a = pb.neeA[path], b = pb.neeB[path], c = pb.neeC[path];
+        // RGB: a hit nearer than distToLight - 1e-4 contributes nothing; skip its material.
+        if (!SPECTRAL && skipOccluded && !(h.t >= c.z - 1e-4f)) continue;
         const ShadowHit s = shadowHitOf(sc, sr, h, pb.counters);
         if (h.id != kMiss) shaded++;
-        const float4 a = pb.neeA[path], b = pb.neeB[path], c = pb.neeC[path];
         const V3 sd = v3(sr.dx, sr.dy, sr.dz);
         if (!SPECTRAL) {
             const V3 brdfDirect = v3(a.x, a.y, a.z);
@@ -700,7 +707,10 @@ __global__ __launch_bounds__(kBlock) void k_shade_rgb(SceneView sc, FrameParams 
                                                 lp.subsurface * evalSubsurfaceRGB(surf, NoLd, NoV, LoVd);
                                 RayRec sr;
                                 sr.ox = so.x; sr.oy = so.y; sr.oz = so.z; sr.pad0 = 0.0f;
-                                sr.dx = sdir.x; sr.dy = sdir.y; sr.dz = sdir.z; sr.pad1 = 0.0f;
+                                // A hit nearer than distToLight - 1e-4 fails the visibility test
+                                // (s_info.t >= distToLight - 1e-4) whatever lies behind it, so the
+                                // traversal may stop at the first such hit without changing the result.
+                                sr.dx = sdir.x; sr.dy = sdir.y; sr.dz = sdir.z; sr.pad1 = fp.shadowEarlyOut ? distToLight - 1e-4f : kNeverStop;
                                 pb.rays[bt.P + path] = sr;
                                 pb.neeA[path] = make_float4(brdfDirect.x, brdfDirect.y, brdfDirect.z, cosTheta);
                                 pb.neeB[path] = make_float4(rayColor.x, rayColor.y, rayColor.z, pdfArea);
@@ -745,7 +755,7 @@ __global__ __launch_bounds__(kBlock) void k_shade_rgb(SceneView sc, FrameParams 
                     if (alive && !lastBounce) {
                         RayRec nr;
                         nr.ox = no.x; nr.oy = no.y; nr.oz = no.z; nr.pad0 = 0.0f;
-                        nr.dx = L.x; nr.dy = L.y; nr.dz = L.z; nr.pad1 = 0.0f;
+                        nr.dx = L.x; nr.dy = L.y; nr.dz = L.z; nr.pad1 = kNeverStop;
                         pb.rays[path] = nr;
                         pb.stA[path] = make_float4(rayColor.x, rayColor.y, rayColor.z, prevBrdfPdf);
                         pb.stB[path] = make_float4(incoming.x, incoming.y, incoming.z, __uint_as_float(seed));
@@ -835,7 +845,7 @@ __global__ __launch_bounds__(kBlock) void k_shade_spectral(SceneView sc, FramePa
                         spec = 1.0f;
                     } else if (Xi < lp.diffuse + lp.specular + lp.transmission) {
                         // dispersion: ior + 0.03 * ((550/lambda)^2 - 1), :1122-1126
-                        float ior = mat.ior + 0.03f * (pow_(550.0f / lambda, 2.0f) - 1.0f);
+                        float ior = mat.ior + 0.03f * (pow2_(550.0f / lambda) - 1.0f);
                         L = sampleTransmission<true>(N, V, info.front_face, ior, roughness, seed);
                         trans = true;
                     } else {
@@ -884,7 +894,7 @@ __global__ __launch_bounds__(kBlock) void k_shade_spectral(SceneView sc, FramePa
                                                lp.subsurface * evalSubsurfaceSpectral(surf, NoLd, NoV, LoVd);
                             RayRec sr;
                             sr.ox = so.x; sr.oy = so.y; sr.oz = so.z; sr.pad0 = 0.0f;
-                            sr.dx = sdir.x; sr.dy = sdir.y; sr.dz = sdir.z; sr.pad1 = 0.0f;
+                            sr.dx = sdir.x; sr.dy = sdir.y; sr.dz = sdir.z; sr.pad1 = kNeverStop;
                             pb.rays[bt.P + path] = sr;
                             pb.neeA[path] = make_float4(brdfDirect, cosTheta, pdf, dot(toLight, toLight));
                             pb.neeB[path] = make_float4(pdfBrdfLd, distToLight, throughput, lambda);
@@ -926,7 +936,7 @@ __global__ __launch_bounds__(kBlock) void k_shade_spectral(SceneView sc, FramePa
                     if (alive && !lastBounce) {
                         RayRec nr;
                         nr.ox = no.x; nr.oy = no.y; nr.oz = no.z; nr.pad0 = 0.0f;
-                        nr.dx = L.x; nr.dy = L.y; nr.dz = L.z; nr.pad1 = 0.0f;
+                        nr.dx = L.x; nr.dy = L.y; nr.dz = L.z; nr.pad1 = kNeverStop;
                         pb.rays[path] = nr;
                         pb.stA[path] = make_float4(throughput, prevBrdfPdf, lambda, 0.0f);
                         sB.x = radiance;
@@ -1034,6 +1044,7 @@ struct rt_ctx {
     int numCUs = 256;
     int maxTreeDepth = 0;
     bool hasAlphaTest = false;
+    bool shadowEarlyOut = true;
     int refillLanes = 32;   // idle lanes that trigger a refill for stages > 0
     int innerShare = 48;    // inner phase runs while >= innerShare/64 of the active lanes sit on inner nodes
 
@@ -1322,16 +1333,16 @@ int runBatch(rt_ctx *ctx, const Batch &bt) {
     for (int b = 0; b <= fp.bounces; ++b) {
         launchTrace(ctx, b & 1, b);
         if (b > 0) {
-            if (spectral) hipLaunchKernelGGL(k_connect<true>, dim3(gShade), dim3(kBlock), 0, ctx->stream, ctx->view, bt, ctx->pb, b, cnt);
-            else hipLaunchKernelGGL(k_connect<false>, dim3(gShade), dim3(kBlock), 0, ctx->stream, ctx->view, bt, ctx->pb, b, cnt);
+            if (spectral) hipLaunchKernelGGL(k_connect<true>, dim3(gShade), dim3(kBlock), 0, ctx->stream, ctx->view, bt, ctx->pb, b, cnt, fp.shadowEarlyOut);
+            else hipLaunchKernelGGL(k_connect<false>, dim3(gShade), dim3(kBlock), 0, ctx->stream, ctx->view, bt, ctx->pb, b, cnt, fp.shadowEarlyOut);
         }
         if (spectral) hipLaunchKernelGGL(k_shade_spectral, dim3(gShade), dim3(kBlock), 0, ctx->stream, ctx->view, fp, bt, ctx->pb, b, cnt);
         else hipLaunchKernelGGL(k_shade_rgb, dim3(gShade), dim3(kBlock), 0, ctx->stream, ctx->view, fp, bt, ctx->pb, b, cnt);
     }
     const int last = fp.bounces + 1;
     launchTrace(ctx, -1, last);
-    if (spectral) hipLaunchKernelGGL(k_connect<true>, dim3(gShade), dim3(kBlock), 0, ctx->stream, ctx->view, bt, ctx->pb, last, cnt);
-    else hipLaunchKernelGGL(k_connect<false>, dim3(gShade), dim3(kBlock), 0, ctx->stream, ctx->view, bt, ctx->pb, last, cnt);
+    if (spectral) hipLaunchKernelGGL(k_connect<true>, dim3(gShade), dim3(kBlock), 0, ctx->stream, ctx->view, bt, ctx->pb, last, cnt, fp.shadowEarlyOut);
+    else hipLaunchKernelGGL(k_connect<false>, dim3(gShade), dim3(kBlock), 0, ctx->stream, ctx->view, bt, ctx->pb, last, cnt, fp.shadowEarlyOut);
 
     const int gRes = gridFor(ctx, fp.npt, 16);
     if (spectral) hipLaunchKernelGGL(k_resolve<true>, dim3(gRes), dim3(kBlock), 0, ctx->stream, fp, bt, ctx->pb, ctx->dAccum, ctx->dPartial);
@@ -1511,6 +1522,7 @@ int rt_set_frame(rt_ctx *ctx, const rt_camera *cam, const float sky_linear[3], i
     fp.tilesY = (ctx->H + 7) / 8;
     fp.npt = (uint32_t)fp.tilesX * (uint32_t)fp.tilesY * 64u;
     fp.S = (uint32_t)fp.ssq * (uint32_t)fp.ssq;
+    fp.shadowEarlyOut = (ctx->shadowEarlyOut && type == RT_TYPE_RGB) ? 1 : 0;
     ctx->type = type;
     ctx->frameSet = true;
     return RT_OK;
@@ -1678,6 +1690,26 @@ int rt_reset_stats(rt_ctx *ctx) {
     ctx->traceLaunches = 0;
     ctx->cameraSamples = 0;
     return RT_OK;
+}
+
+int rt_set_option(rt_ctx *ctx, int option, int value) {
+    if (ctx == nullptr) return RT_ERR_INVALID;
+    switch (option) {
+        case RT_OPT_SHADOW_EARLY_OUT:
+            ctx->shadowEarlyOut = value != 0;
+            ctx->fp.shadowEarlyOut = (ctx->shadowEarlyOut && ctx->type == RT_TYPE_RGB) ? 1 : 0;
+            return RT_OK;
+        case RT_OPT_REFILL_LANES:
+            if (value < 1 || value > 64) return RT_ERR_INVALID;
+            ctx->refillLanes = value;
+            return RT_OK;
+        case RT_OPT_INNER_SHARE:
+            if (value < 1 || value > 64) return RT_ERR_INVALID;
+            ctx->innerShare = value;
+            return RT_OK;
+        default:
+            return RT_ERR_INVALID;
+    }
 }
 
 int rt_set_counters(rt_ctx *ctx, int enabled) {

@@ -18,7 +18,9 @@
 //   normalize(v)  : v * (1 / sqrt(dot(v,v)))  (one division, three products)
 //   dot           : ((a.x*b.x + a.y*b.y) + a.z*b.z), no fused multiply-add
 //   mix(a,b,t)    : a*(1-t) + b*t
-//   pow(x,y)      : exp(y*log(x)) for x > 0; 0 for x == 0; NaN for x < 0
+//   pow(x,y)      : exp(y*log(x)) for x > 0; 0 for x == 0; NaN for x < 0;
+//                   the integer powers the shaders use are products instead:
+//                   pow(x,5) = ((x*x)*(x*x))*x and pow(x,2) = x*x
 //   sin/cos       : 3-term Cody-Waite reduction by pi/2 + degree-7/8 polynomials
 //   exp/log       : Cephes single-precision kernels (about 1 ulp without FMA)
 #pragma once
@@ -133,6 +135,11 @@ RT_FN float pow_(float x, float y) {
     if (x == 0.0f) return 0.0f;
     return exp_(y * log_(x));
 }
+RT_FN float pow5_(float x) {
+    float x2 = x * x;
+    return (x2 * x2) * x;
+}
+RT_FN float pow2_(float x) { return x * x; }
 
 // sin and cos of x (radians) for |x| up to a few thousand.
 RT_FN void sincos_(float x, float *s, float *c) {

@@ -108,14 +108,37 @@ def test_frame_stride_and_batching(backend):
     assert np.array_equal(three, want)
 
 
+def test_shadow_early_out_does_not_change_the_image(backend):
+    W, H = 64, 48
+    scene, cam = _setup(backend, "cornell_knot", dict(nu=128, nv=24), W, H, 4, 4, capi.RT_TYPE_RGB)
+    images = []
+    for flag in (1, 0):
+        backend.set_option(capi.RT_OPT_SHADOW_EARLY_OUT, flag)
+        backend.set_frame(cam, scene.sky, capi.RT_TYPE_RGB)
+        backend.reset_accum()
+        backend.set_counters(True)
+        backend.reset_stats()
+        backend.render(1, 3, 1)
+        images.append((backend.readback()[0], backend.stats()))
+        backend.set_counters(False)
+    backend.set_option(capi.RT_OPT_SHADOW_EARLY_OUT, 1)
+    assert np.array_equal(images[0][0], images[1][0])
+    assert images[0][1]["rays"] == images[1][1]["rays"]
+    assert images[0][1]["node_visits"] < images[1][1]["node_visits"]   # it does save work
+
+
 def test_ray_counts_match_checker(backend):
     W, H = 48, 48
     scene, cam = _setup(backend, "mixed", dict(nu=64, nv=12), W, H, 4, 4, capi.RT_TYPE_RGB)
+    # Full closest-hit walks for every ray, so the visit counts are the reference algorithm's.
+    backend.set_option(capi.RT_OPT_SHADOW_EARLY_OUT, 0)
+    backend.set_frame(cam, scene.sky, capi.RT_TYPE_RGB)
     backend.set_counters(True)
     backend.reset_stats()
     backend.render(1, 2, 1)
     st = backend.stats()
     backend.set_counters(False)
+    backend.set_option(capi.RT_OPT_SHADOW_EARLY_OUT, 1)
     _, ost = OracleScene(scene).render(cam, 0, 1, 2, 1)
     assert st["rays"] == ost["rays"]
     assert st["node_visits"] == ost["node_visits"]
