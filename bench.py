@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--nv", type=int, default=213)
     ap.add_argument("--scene", default="cornell_knot")
     ap.add_argument("--spectral", action="store_true")
+    ap.add_argument("--shard", choices=["sample", "tile"], default="sample",
+                    help="N>1: sample-split (frames dealt round-robin) or tile-split (8x8 tiles dealt round-robin)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
     return ap.parse_args()
@@ -74,12 +76,18 @@ def main():
     # The sum buffer is a torch tensor so RCCL can reduce it in place.
     accum = torch.zeros(args.height, args.width, 4, dtype=torch.float32, device=f"cuda:{local_rank}")
     be.bind_accum(accum.data_ptr(), accum.numel())
+    tile_split = distributed and args.shard == "tile"
+    if tile_split:
+        be.set_tile_shard(rank, world)
     be.set_frame(cam, scene.sky, rtype)
 
     def step(k):
-        # Frames of this step for this rank: sample-split over ranks, fresh frames every step.
-        first = 1 + k * args.spp * world + rank
-        be.render(first_frame=first, n_frames=args.spp, stride=world)
+        if tile_split:
+            # Every rank renders all frames of the step on its own tiles (strong scaling of one image).
+            be.render(first_frame=1 + k * args.spp, n_frames=args.spp, stride=1)
+        else:
+            # Frames of this step for this rank: sample-split over ranks, fresh frames every step.
+            be.render(first_frame=1 + k * args.spp * world + rank, n_frames=args.spp, stride=world)
         be.sync()
         if distributed:
             dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
@@ -146,15 +154,15 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if tile_split else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
                 "workload": f"{args.scene} (procedural dragon-class mesh, {2 * args.nu * args.nv} triangles) in Cornell box, "
-                            f"{args.width}x{args.height}, {args.spp} spp per GPU per step, primary+{args.bounces} bounces, "
+                            f"{args.width}x{args.height}, {args.spp} spp per {'image' if tile_split else 'GPU'} per step, primary+{args.bounces} bounces, "
                             f"{'Spectral' if args.spectral else 'RGB'} NEE+MIS",
-                "sharding": "sample-split frames, scene replicated, RCCL sum-reduce of the fp32 accumulation buffer" if distributed else "single GPU",
+                "sharding": (("tile-split 8x8 tiles" if tile_split else "sample-split frames") + ", scene replicated, RCCL sum-reduce of the fp32 accumulation buffer") if distributed else "single GPU",
                 "rays_per_camera_sample": round(total_rays / max(total_samples, 1), 4),
             },
             "spp_per_s": round(spp_per_s, 3),

@@ -106,12 +106,28 @@ int rt_sync(rt_ctx *ctx);
  * (src/RayTracer.h:39) holds in the reference.  Synchronises. */
 int rt_readback(rt_ctx *ctx, float *rgba_sum, size_t floats, uint32_t *frames);
 
+/* The screen pass of src/main.cpp:36-69 applied to the progressive mean: clamp at 0,
+ * ACES filmic curve, red/green/blue debug colours for NaN/negative/infinite, gamma 1/2.2.
+ * Writes W*H RGBA8 pixels (row 0 = bottom row).  Synchronises. */
+int rt_display_rgba8(rt_ctx *ctx, uint8_t *rgba8, size_t bytes);
+
+/* Checkpoint/resume of the progressive state (no reference counterpart: the reference keeps
+ * it only in two GPU textures and m_frameCount, src/RayTracer.h:24-27): uploads a sum buffer
+ * previously obtained from rt_readback together with its frame count. */
+int rt_restore_accum(rt_ctx *ctx, const float *rgba_sum, size_t floats, uint32_t frames);
+
 /* Device pointer of the sum buffer, for an in-place RCCL reduce by the caller. */
 int rt_accum_device_ptr(rt_ctx *ctx, void **dev_ptr, size_t *floats);
 /* Makes the context accumulate into caller-owned device memory (W*H*4 floats). */
 int rt_bind_accum(rt_ctx *ctx, void *dev_ptr, size_t floats);
 /* Adds `frames` to the frame count after an external reduce merged other ranks' sums. */
 int rt_add_frames(rt_ctx *ctx, uint32_t frames);
+
+/* Tile-split sharding (no reference counterpart): the context renders only the 8x8
+ * pixel tiles whose row-major index i has i % stride == offset; other pixels of its
+ * sum buffer stay untouched (zero after rt_resize / rt_reset_accum), so the shards'
+ * buffers add up to the full image.  stride = 1 renders everything (default). */
+int rt_set_tile_shard(rt_ctx *ctx, uint32_t offset, uint32_t stride);
 
 /* Parity hook (no reference counterpart: the reference never outputs IDs): closest
  * hit of the first camera sample's ray of frame `frame`, sample index 0, per pixel.

@@ -1078,6 +1078,25 @@ int orc_render(const orc_scene *s, const Camera *cam, const float sky[3], int ty
     return 0;
 }
 
+// Screen pass of src/main.cpp:36-69 on a mean image (rgba float, alpha ignored) -> RGBA8.
+int orc_display(const float *rgba_mean, size_t pixels, uint8_t *rgba8) {
+    for (size_t i = 0; i < pixels; ++i) {
+        V3 c = rtm::vmax(v3(rgba_mean[i * 4], rgba_mean[i * 4 + 1], rgba_mean[i * 4 + 2]), v3s(0.0f));
+        c = (c * (2.51f * c + v3s(0.03f))) / (c * (2.43f * c + v3s(0.59f)) + v3s(0.14f));
+        c = rtm::vclamp(c, 0.0f, 1.0f);
+        V3 o;
+        if (c.x != c.x || c.y != c.y || c.z != c.z) o = v3(1.0f, 0.0f, 0.0f);
+        else if (c.x < 0.0f || c.y < 0.0f || c.z < 0.0f) o = v3(0.0f, 1.0f, 0.0f);
+        else if (rtm::abs_(c.x) == rtm::inf() || rtm::abs_(c.y) == rtm::inf() || rtm::abs_(c.z) == rtm::inf()) o = v3(0.0f, 0.0f, 1.0f);
+        else o = v3(rtm::pow_(c.x, 1.0f / 2.2f), rtm::pow_(c.y, 1.0f / 2.2f), rtm::pow_(c.z, 1.0f / 2.2f));
+        rgba8[i * 4 + 0] = (uint8_t)(o.x * 255.0f + 0.5f);
+        rgba8[i * 4 + 1] = (uint8_t)(o.y * 255.0f + 0.5f);
+        rgba8[i * 4 + 2] = (uint8_t)(o.z * 255.0f + 0.5f);
+        rgba8[i * 4 + 3] = 255;
+    }
+    return 0;
+}
+
 // Small known-answer hooks.
 uint32_t orc_pcg(uint32_t v) { return rtm::pcg(v); }
 uint32_t orc_hash_seed(uint32_t x, uint32_t y, uint32_t frame, uint32_t sample) { return rtm::hash_seed(x, y, frame, sample); }

@@ -19,8 +19,8 @@ RT_OPT_SHADOW_EARLY_OUT, RT_OPT_REFILL_LANES, RT_OPT_INNER_SHARE = 1, 2, 3
 # Every symbol include/rt_hip.h declares.
 HIP_SYMBOLS = [
     "rt_create", "rt_destroy", "rt_upload", "rt_commit_scene", "rt_resize", "rt_set_frame", "rt_render",
-    "rt_reset_accum", "rt_sync", "rt_readback", "rt_accum_device_ptr", "rt_bind_accum", "rt_add_frames",
-    "rt_trace_primary", "rt_get_stats", "rt_reset_stats", "rt_set_counters", "rt_set_option", "rt_strerror", "rt_last_hip_error",
+    "rt_reset_accum", "rt_sync", "rt_readback", "rt_display_rgba8", "rt_restore_accum", "rt_accum_device_ptr", "rt_bind_accum", "rt_add_frames",
+    "rt_trace_primary", "rt_get_stats", "rt_reset_stats", "rt_set_counters", "rt_set_option", "rt_set_tile_shard", "rt_strerror", "rt_last_hip_error",
 ]
 # Every symbol include/rt_host.h declares.
 HOST_SYMBOLS = [
@@ -84,6 +84,8 @@ hip.rt_render.argtypes = [_vp, _u32, _u32, _u32]
 hip.rt_reset_accum.argtypes = [_vp]
 hip.rt_sync.argtypes = [_vp]
 hip.rt_readback.argtypes = [_vp, _vp, _sz, C.POINTER(_u32)]
+hip.rt_display_rgba8.argtypes = [_vp, _vp, _sz]
+hip.rt_restore_accum.argtypes = [_vp, _vp, _sz, _u32]
 hip.rt_accum_device_ptr.argtypes = [_vp, C.POINTER(_vp), C.POINTER(_sz)]
 hip.rt_bind_accum.argtypes = [_vp, _vp, _sz]
 hip.rt_add_frames.argtypes = [_vp, _u32]
@@ -92,6 +94,7 @@ hip.rt_get_stats.argtypes = [_vp, C.POINTER(RtStats)]
 hip.rt_reset_stats.argtypes = [_vp]
 hip.rt_set_counters.argtypes = [_vp, _i]
 hip.rt_set_option.argtypes = [_vp, _i, _i]
+hip.rt_set_tile_shard.argtypes = [_vp, _u32, _u32]
 hip.rt_strerror.argtypes = [_i]
 hip.rt_strerror.restype = C.c_char_p
 hip.rt_last_hip_error.argtypes = [_vp]
@@ -209,6 +212,15 @@ class Backend:
         self._check(hip.rt_readback(self._ctx, out.ctypes.data_as(_vp), out.size, C.byref(frames)))
         return out, frames.value
 
+    def display_rgba8(self):
+        out = np.empty((self.height, self.width, 4), dtype=np.uint8)
+        self._check(hip.rt_display_rgba8(self._ctx, out.ctypes.data_as(_vp), out.size))
+        return out
+
+    def restore_accum(self, rgba_sum, frames):
+        a = np.ascontiguousarray(rgba_sum, dtype=np.float32)
+        self._check(hip.rt_restore_accum(self._ctx, a.ctypes.data_as(_vp), a.size, frames))
+
     def accum_device_ptr(self):
         ptr, n = _vp(), _sz()
         self._check(hip.rt_accum_device_ptr(self._ctx, C.byref(ptr), C.byref(n)))
@@ -236,6 +248,9 @@ class Backend:
 
     def reset_stats(self):
         self._check(hip.rt_reset_stats(self._ctx))
+
+    def set_tile_shard(self, offset, stride):
+        self._check(hip.rt_set_tile_shard(self._ctx, offset, stride))
 
     def set_option(self, option, value):
         self._check(hip.rt_set_option(self._ctx, option, int(value)))

@@ -63,6 +63,9 @@ struct FrameParams {
     uint32_t npt;       // padded pixels per sample plane: tilesX*tilesY*64
     uint32_t S;         // samples per frame = ssq*ssq
     int32_t shadowEarlyOut;   // RGB shadow rays stop at the first hit that already proves occlusion
+    // Tile-split sharding: this context renders only the 8x8 tiles whose row-major
+    // index i satisfies i % tileStride == tileOffset (all tiles when stride is 1).
+    uint32_t tileOffset, tileStride;
 };
 
 struct Batch {
@@ -127,7 +130,7 @@ __device__ __forceinline__ bool pathPixel(const FrameParams &fp, uint32_t q, int
     uint32_t tile = q >> 6, l = q & 63u;
     x = (int)(tile % (uint32_t)fp.tilesX) * 8 + (int)(l & 7u);
     y = (int)(tile / (uint32_t)fp.tilesX) * 8 + (int)(l >> 3);
-    return x < fp.W && y < fp.H;
+    return x < fp.W && y < fp.H && (tile % fp.tileStride) == fp.tileOffset;
 }
 
 // ---- k_generate -----------------------------------------------------------------------
@@ -320,8 +323,8 @@ __device__ __forceinline__ void intersectPrimitives(const SceneView &sc, LaneRay
 // keeps whole 64-ray packets together, which is what coherent camera rays want;
 // incoherent rays run best around 32).  The traversal stack of each lane lives
 // in LDS ([entry][lane], conflict free).
-template <bool COUNT, int STACK, bool ALPHA>
-__global__ __launch_bounds__(kBlock, (STACK <= 20 ? RT_W20 : STACK <= 24 ? 6 : 5)) void k_trace(SceneView sc, PathBuffers pb, int extParity, int stage, int refillLanes, int innerShare) {
+template <bool COUNT, int STACK, bool ALPHA, bool PRIMS>
+__global__ __launch_bounds__(kBlock, (STACK <= 20 ? (PRIMS || ALPHA ? 7 : RT_W20) : STACK <= 24 ? 6 : 5)) void k_trace(SceneView sc, PathBuffers pb, int extParity, int stage, int refillLanes, int innerShare) {
     __shared__ int32_t stackLds[kBlock / 64][STACK][64];
     const uint32_t lane = laneId();
     int32_t(*stack)[64] = stackLds[threadIdx.x >> 6];
@@ -382,12 +385,23 @@ __global__ __launch_bounds__(kBlock, (STACK <= 20 ? RT_W20 : STACK <= 24 ? 6 : 5
                     r.rd = v3(r1.x, r1.y, r1.z);
                     r.inv = v3(1.0f / r.rd.x, 1.0f / r.rd.y, 1.0f / r.rd.z);
                     r.tStop = r1.w;
-                    intersectPrimitives<COUNT>(sc, r, cntTris);
-                    active = !(r.closest < r.tStop) && enterModel(sc, r, 0);
-                    if (!active) {   // no models (or already occluded): the primitive result is final
+                    if (PRIMS) {
+                        intersectPrimitives<COUNT>(sc, r, cntTris);
+                        active = !(r.closest < r.tStop) && enterModel(sc, r, 0);
+                        if (!active) {   // no models (or already occluded): the primitive result is final
+                            HitRec rec;
+                            rec.t = r.closest; rec.u = r.bestU; rec.v = r.bestV; rec.id = r.bestId;
+                            *reinterpret_cast<float4 *>(&pb.hits[r.slot]) = *reinterpret_cast<const float4 *>(&rec);
+                        }
+                    } else {
+                        // Without analytic primitives the record starts as a miss and is
+                        // overwritten whenever a model ends with a closer hit, so the best
+                        // hit need not be carried in registers.
+                        r.closest = 1e20f;
                         HitRec rec;
-                        rec.t = r.closest; rec.u = r.bestU; rec.v = r.bestV; rec.id = r.bestId;
+                        rec.t = 1e20f; rec.u = 0.0f; rec.v = 0.0f; rec.id = kMiss;
                         *reinterpret_cast<float4 *>(&pb.hits[r.slot]) = *reinterpret_cast<const float4 *>(&rec);
+                        active = enterModel(sc, r, 0);
                     }
                 }
             }
@@ -466,16 +480,24 @@ __global__ __launch_bounds__(kBlock, (STACK <= 20 ? RT_W20 : STACK <= 24 ? 6 : 5
             } else {
                 if (r.mBest != kMiss) {
                     r.closest = r.tModel;
-                    r.bestId = r.mBest;
-                    r.bestU = r.mU;
-                    r.bestV = r.mV;
+                    if (PRIMS) {
+                        r.bestId = r.mBest;
+                        r.bestU = r.mU;
+                        r.bestV = r.mV;
+                    } else {
+                        HitRec rec;
+                        rec.t = r.tModel; rec.u = r.mU; rec.v = r.mV; rec.id = r.mBest;
+                        *reinterpret_cast<float4 *>(&pb.hits[r.slot]) = *reinterpret_cast<const float4 *>(&rec);
+                    }
                 }
                 if (occluded || !enterModel(sc, r, r.model + 1)) {
-                    uint32_t id = r.bestId;
-                    if (id != kMiss && (id & kPrimBit) == 0u && !(r.afterPrimitives > r.closest)) id |= kNoTexBit;
-                    HitRec rec;
-                    rec.t = r.closest; rec.u = r.bestU; rec.v = r.bestV; rec.id = id;
-                    *reinterpret_cast<float4 *>(&pb.hits[r.slot]) = *reinterpret_cast<const float4 *>(&rec);
+                    if (PRIMS) {
+                        uint32_t id = r.bestId;
+                        if (id != kMiss && (id & kPrimBit) == 0u && !(r.afterPrimitives > r.closest)) id |= kNoTexBit;
+                        HitRec rec;
+                        rec.t = r.closest; rec.u = r.bestU; rec.v = r.bestV; rec.id = id;
+                        *reinterpret_cast<float4 *>(&pb.hits[r.slot]) = *reinterpret_cast<const float4 *>(&rec);
+                    }
                     active = false;
                 }
             }
@@ -1003,6 +1025,27 @@ __global__ __launch_bounds__(kBlock) void k_resolve(FrameParams fp, Batch bt, Pa
     }
 }
 
+// ---- k_display ---------------------------------------------------------------------------
+// The reference's screen pass (src/main.cpp:36-69) on the progressive mean:
+// clamp below at 0, ACES filmic curve, NaN / negative / infinite debug colours,
+// gamma 1/2.2; written as 8-bit RGBA (round to nearest).
+__global__ __launch_bounds__(kBlock) void k_display(const float4 *accum, uchar4 *out, uint32_t pixels) {
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < pixels; i += gridDim.x * kBlock) {
+        const float4 a = accum[i];
+        const float n = a.w > 0.0f ? a.w : 1.0f;
+        V3 c = vmax(v3(a.x / n, a.y / n, a.z / n), v3s(0.0f));
+        c = (c * (2.51f * c + v3s(0.03f))) / (c * (2.43f * c + v3s(0.59f)) + v3s(0.14f));
+        c = vclamp(c, 0.0f, 1.0f);
+        V3 o;
+        if (c.x != c.x || c.y != c.y || c.z != c.z) o = v3(1.0f, 0.0f, 0.0f);
+        else if (c.x < 0.0f || c.y < 0.0f || c.z < 0.0f) o = v3(0.0f, 1.0f, 0.0f);
+        else if (abs_(c.x) == inf() || abs_(c.y) == inf() || abs_(c.z) == inf()) o = v3(0.0f, 0.0f, 1.0f);
+        else o = v3(pow_(c.x, 1.0f / 2.2f), pow_(c.y, 1.0f / 2.2f), pow_(c.z, 1.0f / 2.2f));
+        out[i] = make_uchar4((unsigned char)(o.x * 255.0f + 0.5f), (unsigned char)(o.y * 255.0f + 0.5f),
+                             (unsigned char)(o.z * 255.0f + 0.5f), 255);
+    }
+}
+
 }  // namespace
 
 // ============================================================================================
@@ -1045,6 +1088,7 @@ struct rt_ctx {
     int maxTreeDepth = 0;
     bool hasAlphaTest = false;
     bool shadowEarlyOut = true;
+    uint32_t tileOffset = 0, tileStride = 1;
     int refillLanes = 32;   // idle lanes that trigger a refill for stages > 0
     int innerShare = 48;    // inner phase runs while >= innerShare/64 of the active lanes sit on inner nodes
 
@@ -1306,12 +1350,15 @@ void launchTrace(rt_ctx *ctx, int extParity, int stage) {
     // Kernel variant: visit counting, LDS stack depth (24 entries let 6 blocks share a
     // CU's LDS instead of 5), alpha-cut support only when some triangle needs it.
     using TraceFn = void (*)(SceneView, PathBuffers, int, int, int, int);
-    static const TraceFn variants[2][3][2] = {
-        {{k_trace<false, 20, false>, k_trace<false, 20, true>}, {k_trace<false, 24, false>, k_trace<false, 24, true>}, {k_trace<false, kStackDepth, false>, k_trace<false, kStackDepth, true>}},
-        {{k_trace<true, 20, false>, k_trace<true, 20, true>}, {k_trace<true, 24, false>, k_trace<true, 24, true>}, {k_trace<true, kStackDepth, false>, k_trace<true, kStackDepth, true>}}};
+#define RT_TRACE_ROW(C, S) {{k_trace<C, S, false, false>, k_trace<C, S, false, true>}, {k_trace<C, S, true, false>, k_trace<C, S, true, true>}}
+    static const TraceFn variants[2][3][2][2] = {{RT_TRACE_ROW(false, 20), RT_TRACE_ROW(false, 24), RT_TRACE_ROW(false, kStackDepth)},
+                                                 {RT_TRACE_ROW(true, 20), RT_TRACE_ROW(true, 24), RT_TRACE_ROW(true, kStackDepth)}};
+#undef RT_TRACE_ROW
     const int depthClass = ctx->maxTreeDepth <= 20 ? 0 : ctx->maxTreeDepth <= 24 ? 1 : 2;
-    const TraceFn fn = variants[ctx->countersOn ? 1 : 0][depthClass][ctx->hasAlphaTest ? 1 : 0];
-    const int grid = ctx->numCUs * (depthClass == 0 ? RT_W20 : depthClass == 1 ? 6 : 5);
+    const bool prims = ctx->objectCount > 0;
+    const TraceFn fn = variants[ctx->countersOn ? 1 : 0][depthClass][ctx->hasAlphaTest ? 1 : 0][prims ? 1 : 0];
+    const int wavesPerSimd = depthClass == 0 ? ((prims || ctx->hasAlphaTest) ? 7 : RT_W20) : depthClass == 1 ? 6 : 5;
+    const int grid = ctx->numCUs * wavesPerSimd;
     hipLaunchKernelGGL(fn, dim3(grid), dim3(kBlock), 0, ctx->stream, ctx->view, ctx->pb, extParity, stage, refill, ctx->innerShare);
     if (e1) hipEventRecord(e1, ctx->stream);
     if (e0 && e1) ctx->traceEvents.push_back({e0, e1});
@@ -1523,6 +1570,8 @@ int rt_set_frame(rt_ctx *ctx, const rt_camera *cam, const float sky_linear[3], i
     fp.npt = (uint32_t)fp.tilesX * (uint32_t)fp.tilesY * 64u;
     fp.S = (uint32_t)fp.ssq * (uint32_t)fp.ssq;
     fp.shadowEarlyOut = (ctx->shadowEarlyOut && type == RT_TYPE_RGB) ? 1 : 0;
+    fp.tileOffset = ctx->tileOffset;
+    fp.tileStride = ctx->tileStride;
     ctx->type = type;
     ctx->frameSet = true;
     return RT_OK;
@@ -1555,7 +1604,15 @@ int rt_render(rt_ctx *ctx, uint32_t first_frame, uint32_t n_frames, uint32_t fra
     if (e1) hipEventRecord(e1, ctx->stream);
     if (e0 && e1) ctx->renderEvents.push_back({e0, e1});
     ctx->framesAccum += n_frames;
-    ctx->cameraSamples += totalPlanes * (uint64_t)ctx->W * (uint64_t)ctx->H;
+    uint64_t ownedPixels = (uint64_t)ctx->W * (uint64_t)ctx->H;
+    if (fp.tileStride > 1) {
+        ownedPixels = 0;
+        for (uint32_t tile = fp.tileOffset; tile < (uint32_t)fp.tilesX * (uint32_t)fp.tilesY; tile += fp.tileStride) {
+            const int x0 = (int)(tile % (uint32_t)fp.tilesX) * 8, y0 = (int)(tile / (uint32_t)fp.tilesX) * 8;
+            ownedPixels += (uint64_t)std::min(8, fp.W - x0) * (uint64_t)std::min(8, fp.H - y0);
+        }
+    }
+    ctx->cameraSamples += totalPlanes * ownedPixels;
     return RT_OK;
 }
 
@@ -1584,6 +1641,36 @@ int rt_readback(rt_ctx *ctx, float *rgba_sum, size_t floats, uint32_t *frames) {
     if (rc != RT_OK) return rc;
     RT_HIP(hipMemcpy(rgba_sum, ctx->dAccum, floats * sizeof(float), hipMemcpyDeviceToHost));
     if (frames) *frames = ctx->framesAccum;
+    return RT_OK;
+}
+
+int rt_display_rgba8(rt_ctx *ctx, uint8_t *rgba8, size_t bytes) {
+    if (ctx == nullptr || rgba8 == nullptr) return RT_ERR_INVALID;
+    if (ctx->dAccum == nullptr) return RT_ERR_STATE;
+    const size_t px = (size_t)ctx->W * ctx->H;
+    if (bytes != px * 4) return RT_ERR_INVALID;
+    RT_HIP(hipSetDevice(ctx->device));
+    uchar4 *dOut = nullptr;
+    RT_HIP(hipMalloc(reinterpret_cast<void **>(&dOut), px * sizeof(uchar4)));
+    hipLaunchKernelGGL(k_display, dim3(gridFor(ctx, px, 8)), dim3(kBlock), 0, ctx->stream, ctx->dAccum, dOut, (uint32_t)px);
+    hipError_t e = hipMemcpyAsync(rgba8, dOut, bytes, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    hipFree(dOut);
+    if (e != hipSuccess) {
+        ctx->hipError = std::string("rt_display_rgba8: ") + hipGetErrorString(e);
+        return RT_ERR_HIP;
+    }
+    return RT_OK;
+}
+
+int rt_restore_accum(rt_ctx *ctx, const float *rgba_sum, size_t floats, uint32_t frames) {
+    if (ctx == nullptr || rgba_sum == nullptr) return RT_ERR_INVALID;
+    if (ctx->dAccum == nullptr) return RT_ERR_STATE;
+    if (floats != (size_t)ctx->W * ctx->H * 4) return RT_ERR_INVALID;
+    RT_HIP(hipSetDevice(ctx->device));
+    RT_HIP(hipStreamSynchronize(ctx->stream));
+    RT_HIP(hipMemcpy(ctx->dAccum, rgba_sum, floats * sizeof(float), hipMemcpyHostToDevice));
+    ctx->framesAccum = frames;
     return RT_OK;
 }
 
@@ -1689,6 +1776,15 @@ int rt_reset_stats(rt_ctx *ctx) {
     ctx->traceMs = ctx->totalMs = 0.0;
     ctx->traceLaunches = 0;
     ctx->cameraSamples = 0;
+    return RT_OK;
+}
+
+int rt_set_tile_shard(rt_ctx *ctx, uint32_t offset, uint32_t stride) {
+    if (ctx == nullptr || stride == 0 || offset >= stride) return RT_ERR_INVALID;
+    ctx->tileOffset = offset;
+    ctx->tileStride = stride;
+    ctx->fp.tileOffset = offset;
+    ctx->fp.tileStride = stride;
     return RT_OK;
 }
 

@@ -27,8 +27,17 @@ lib.orc_math.argtypes = [C.c_int, C.c_float, C.c_float]
 lib.orc_math.restype = C.c_float
 lib.orc_camera_ray.argtypes = [C.POINTER(RtCamera), C.c_int, C.c_int, C.c_uint32, _fp]
 lib.orc_hit.argtypes = [_vp, _fp, _fp, _fp]
+lib.orc_display.argtypes = [_vp, C.c_size_t, _vp]
 
 THREADS = min(8, os.cpu_count() or 1)
+
+
+def display(rgba_mean):
+    """Screen pass of the reference's main.cpp on a float mean image -> RGBA8."""
+    a = np.ascontiguousarray(rgba_mean, dtype=np.float32)
+    out = np.empty(a.shape[:-1] + (4,), np.uint8)
+    lib.orc_display(a.ctypes.data_as(_vp), a.size // 4, out.ctypes.data_as(_vp))
+    return out
 
 
 class OracleScene:

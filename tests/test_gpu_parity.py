@@ -127,6 +127,33 @@ def test_shadow_early_out_does_not_change_the_image(backend):
     assert images[0][1]["node_visits"] < images[1][1]["node_visits"]   # it does save work
 
 
+def test_tile_split_shards_partition_the_image(backend):
+    """Tile-split: shard k of 3 renders tiles k, k+3, ...; each pixel is owned by exactly one shard and
+    carries exactly the full render's value (no addition across shards, so bit-exact)."""
+    W, H = 70, 45   # ragged on purpose
+    scene, cam = _setup(backend, "mixed", dict(nu=64, nv=12), W, H, 3, 4, capi.RT_TYPE_RGB)
+    backend.render(1, 2, 1)
+    full, _ = backend.readback()
+    total = np.zeros_like(full)
+    owners = np.zeros((H, W), np.int32)
+    samples = 0
+    for k in range(3):
+        backend.set_tile_shard(k, 3)
+        backend.set_frame(cam, scene.sky, capi.RT_TYPE_RGB)
+        backend.reset_accum()
+        backend.reset_stats()
+        backend.render(1, 2, 1)
+        part, _ = backend.readback()
+        samples += backend.stats()["camera_samples"]
+        owners += (part[..., 3] > 0)
+        total += part
+    backend.set_tile_shard(0, 1)
+    backend.set_frame(cam, scene.sky, capi.RT_TYPE_RGB)
+    assert (owners == 1).all()
+    assert np.array_equal(total, full)
+    assert samples == W * H * 2 * 4
+
+
 def test_ray_counts_match_checker(backend):
     W, H = 48, 48
     scene, cam = _setup(backend, "mixed", dict(nu=64, nv=12), W, H, 4, 4, capi.RT_TYPE_RGB)
@@ -245,3 +272,38 @@ def test_full_size_radiance_band_and_properties(backend, dragon_class):
     even, _ = backend.readback()
     assert np.allclose(odd[..., :3] + even[..., :3], four[..., :3], rtol=1e-5, atol=1e-6)
     assert ((odd + even)[..., 3] == 4).all()
+
+
+# ---- display pass and checkpoint/resume ---------------------------------------------------------
+def test_display_pass_and_resume(backend):
+    import oracle_binding
+
+    W, H = 56, 40
+    scene, cam = _setup(backend, "roughness_demo", {}, W, H, 4, 4, capi.RT_TYPE_RGB)
+    backend.render(1, 3, 1)
+    rgba, n = backend.readback()
+    got = backend.display_rgba8()
+    mean = rgba.copy()
+    mean[..., :3] /= np.float32(n)
+    assert np.array_equal(got, oracle_binding.display(mean))
+    assert got[..., :3].std() > 5          # a real picture, not a constant
+    # +inf turns the ACES quotient into NaN; under the pinned clamp (minNum/maxNum: a NaN
+    # operand yields the other operand) that becomes 0, so the pixel is black, not the
+    # red NaN marker a driver with NaN-propagating clamp would show.
+    probe = np.zeros((H, W, 4), np.float32)
+    probe[..., 3] = 1
+    probe[0, 0, :3] = np.inf
+    probe[0, 1, :3] = [0.18, 0.18, 0.18]
+    backend.restore_accum(probe, 1)
+    shown = backend.display_rgba8()
+    assert np.array_equal(shown, oracle_binding.display(probe))
+    assert tuple(shown[0, 0]) == (0, 0, 0, 255)
+    assert tuple(shown[0, 1]) == tuple(oracle_binding.display(probe)[0, 1]) and shown[0, 1, 0] > 80
+    # resume: restore the 3-frame sum and continue with frames 4..5 == rendering 1..5 in one go
+    backend.restore_accum(rgba, n)
+    backend.render(4, 2, 1)
+    resumed, n2 = backend.readback()
+    backend.reset_accum()
+    backend.render(1, 5, 1)
+    straight, n3 = backend.readback()
+    assert n2 == n3 == 5 and np.array_equal(resumed, straight)

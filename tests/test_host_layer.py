@@ -18,7 +18,7 @@ def i32(words):
 def test_abi_exports_every_declared_symbol():
     for header, lib, declared in (("rt_hip.h", capi.hip, capi.HIP_SYMBOLS), ("rt_host.h", capi.host, capi.HOST_SYMBOLS)):
         text = open(os.path.join(ROOT, "include", header)).read()
-        names = set(re.findall(r"\b(rth?_[a-z_]+)\s*\(", text))
+        names = set(re.findall(r"\b(rth?_[a-z0-9_]+)\s*\(", text))
         assert names == set(declared), (header, names ^ set(declared))
         for n in declared:
             assert hasattr(lib, n), n
