@@ -136,6 +136,7 @@ def main():
         total_rays, total_samples = float(st["rays"]), float(st["camera_samples"])
 
     if rank == 0:
+        triangles = sum(scene.model_stats(m)["triangles"] for m in range(scene.models_count))
         mrays = total_rays / elapsed / 1e6
         pixels = args.width * args.height
         spp_per_s = total_samples / pixels / elapsed
@@ -145,6 +146,7 @@ def main():
         trace_s = st["trace_ms"] / 1e3
         launches = max(st["trace_launches"], 1)
         achieved = st["rays"] * b_ray / max(trace_s, 1e-12) / 1e9
+        traffic, traffic_note = measured_traffic(args)
         out = {
             "metric": "Mrays/s",
             "value": round(mrays, 3),
@@ -159,7 +161,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"{args.scene} (procedural dragon-class mesh, {2 * args.nu * args.nv} triangles) in Cornell box, "
+                "workload": f"{args.scene} ({'procedural dragon-class mesh, ' if 'knot' in args.scene else ''}{triangles} triangles in {scene.models_count} models), "
                             f"{args.width}x{args.height}, {args.spp} spp per {'image' if tile_split else 'GPU'} per step, primary+{args.bounces} bounces, "
                             f"{'Spectral' if args.spectral else 'RGB'} NEE+MIS",
                 "sharding": (("tile-split 8x8 tiles" if tile_split else "sample-split frames") + ", scene replicated, RCCL sum-reduce of the fp32 accumulation buffer") if distributed else "single GPU",
@@ -174,7 +176,8 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_note": traffic_note,
                 "bytes_per_ray": round(b_ray, 1),
                 "nodes_per_ray": round(nodes_per_ray, 3),
                 "tris_per_ray": round(tris_per_ray, 3),
@@ -193,6 +196,22 @@ def main():
     be.close()
     if distributed:
         dist.destroy_process_group()
+
+
+def measured_traffic(args):
+    """HBM-side bytes per k_trace launch from the committed PMC passes (profiles/r01_hbm_traffic.json).
+    Counters cannot be read from inside this process, so the figure is the one measured with rocprofv3
+    on this same command; it is only reported for the default workload it was measured on."""
+    path = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+    default = (args.scene == "cornell_knot" and not args.spectral and (args.width, args.height, args.spp, args.bounces, args.nu, args.nv) == (1920, 1080, 64, 4, 2048, 213))
+    if not default or not os.path.exists(path):
+        return None, "not measured for this workload"
+    with open(path) as f:
+        data = json.load(f)
+    for name, k in data["kernels"].items():
+        if name.startswith("k_trace<false"):
+            return k["fetch_bytes"] + k["write_bytes"], "bytes per launch, rocprofv3 FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE, profiles/r01_hbm_traffic.json"
+    return None, "k_trace not found in profiles/r01_hbm_traffic.json"
 
 
 def cpu_baseline(args, scene, cam, rtype):
