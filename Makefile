@@ -15,7 +15,7 @@ HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-
             -fno-fast-math -Wall -Wno-unused-function -Wno-unused-result -Wno-unused-value -Iinclude -I$(CSRC)
 HOSTFLAGS := -std=c++17 -O2 -fPIC -ffp-contract=off -Wall -Wextra -Wno-unused-parameter -Iinclude -I$(HOST)
 
-HOST_SRCS := $(HOST)/AABB.cpp $(HOST)/BVHTree.cpp $(HOST)/MeshData.cpp $(HOST)/TraceableObject.cpp $(HOST)/RayScene.cpp \
+HOST_SRCS := $(HOST)/AABB.cpp $(HOST)/BVHTree.cpp $(HOST)/MeshData.cpp $(HOST)/GltfLoader.cpp $(HOST)/TraceableObject.cpp $(HOST)/RayScene.cpp \
              $(HOST)/RaySceneBuilder.cpp $(HOST)/RayTracer.cpp $(HOST)/RayEngine.cpp $(HOST)/ProceduralMesh.cpp \
              $(HOST)/host_capi.cpp $(HOST)/gpu/HipStorage.cpp
 HOST_HDRS := $(wildcard $(HOST)/*.h $(HOST)/gpu/*.h $(HOST)/glm/*.hpp $(HOST)/glm/gtc/*.hpp) include/rt_hip.h include/rt_host.h
@@ -28,7 +28,7 @@ $(LIBDIR)/librt_hip.so: $(CSRC)/rt_hip.hip $(CSRC)/rt_device.h $(CSRC)/rt_bsdf.h
 
 $(LIBDIR)/librt_host.so: $(HOST_SRCS) $(HOST_HDRS) $(LIBDIR)/librt_hip.so
 	@mkdir -p $(LIBDIR)
-	$(CXX) $(HOSTFLAGS) -shared $(HOST_SRCS) -o $@ -L$(LIBDIR) -lrt_hip -Wl,-rpath,'$$ORIGIN'
+	$(CXX) $(HOSTFLAGS) -shared $(HOST_SRCS) -o $@ -L$(LIBDIR) -lrt_hip -lz -Wl,-rpath,'$$ORIGIN'
 
 oracle/liboracle.so: oracle/oracle.cpp oracle/oracle_spectral.inc $(CSRC)/rt_math.h
 	$(MAKE) -C oracle liboracle.so

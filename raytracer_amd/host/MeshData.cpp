@@ -23,11 +23,6 @@ void MeshData::deriveTextureFlags() {
     }
 }
 
-MeshData MeshData::LoadMeshData(std::string modelPath) {
-    std::cerr << "Failed to load " << modelPath << " (glTF ingestion is not built; use the in-memory Model constructor)\n";
-    return {};
-}
-
 void MeshData::Identifier::serialize(gpu::Buffer &out) const {
     out.push(index);
     out.push(materialIndex);

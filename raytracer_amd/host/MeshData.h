@@ -45,8 +45,8 @@ struct MeshData {
     void adoptLights(const MeshData &lights);
     void deriveTextureFlags();
 
-    // glTF ingestion needs tinygltf + stb_image, which are not available; an
-    // unreadable path yields an empty mesh exactly like a failed load in the
-    // reference (src/MeshData.cpp:429-433).
+    // Binary glTF (.glb) ingestion (reference src/MeshData.cpp:419-590), implemented in
+    // GltfLoader.cpp without tinygltf/stb_image.  An unreadable path yields an empty mesh
+    // exactly like a failed load in the reference (src/MeshData.cpp:429-433).
     static MeshData LoadMeshData(std::string modelPath);
 };

@@ -146,7 +146,8 @@ inline mat3::mat3(const mat4 &m) { c[0] = vec3(m[0]); c[1] = vec3(m[1]); c[2] = 
 
 inline vec3 operator*(const mat3 &m, const vec3 &v) { return m[0] * v.x + m[1] * v.y + m[2] * v.z; }
 inline vec3 operator*(const vec3 &v, const mat3 &m) { return vec3(dot(v, m[0]), dot(v, m[1]), dot(v, m[2])); }
-inline vec4 operator*(const mat4 &m, const vec4 &v) { return m[0] * v.x + m[1] * v.y + m[2] * v.z + m[3] * v.w; }
+// glm pairs the four products as (c0*x + c1*y) + (c2*z + c3*w).
+inline vec4 operator*(const mat4 &m, const vec4 &v) { return (m[0] * v.x + m[1] * v.y) + (m[2] * v.z + m[3] * v.w); }
 inline mat4 operator*(const mat4 &a, const mat4 &b) {
     mat4 r(0.0f);
     for (int j = 0; j < 4; ++j) r[j] = a[0] * b[j].x + a[1] * b[j].y + a[2] * b[j].z + a[3] * b[j].w;

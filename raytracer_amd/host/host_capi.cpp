@@ -58,6 +58,25 @@ bool buildNamedScene(RayScene &scene, const std::string &name, const SceneParams
         return true;
     }
     scene.setSkyColor(glm::vec3(0.0f));
+    if (name.rfind("glb:", 0) == 0) {
+        // "glb:a.glb;b.glb": one addModel(path) per file, in order, under a black sky
+        // (the reference's model scene is addModel("cornellBox.glb") + addModel("test1.glb"),
+        // src/main.cpp:145-146).  A file that fails to load makes the whole build fail.
+        size_t at = 4;
+        int loaded = 0;
+        while (at <= name.size()) {
+            size_t stop = name.find(';', at);
+            if (stop == std::string::npos) stop = name.size();
+            if (stop > at) {
+                const size_t before = scene.getModelsCount();
+                scene.addModel(name.substr(at, stop - at));
+                if (scene.getModelsCount() == before) return false;
+                ++loaded;
+            }
+            at = stop + 1;
+        }
+        return loaded > 0;
+    }
     if (name == "cornell_quads") {
         RaySceneBuilder::BuildCornellBox(scene, kBoxPos, 2.0f, 0.6f, 15.0f, true);
         Material metal;

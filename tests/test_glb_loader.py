@@ -1,0 +1,229 @@
+"""CPU tests of binary glTF ingestion (MeshData::LoadMeshData, reference src/MeshData.cpp:419-590).
+
+The reference ships no .glb file or loader fixture (its models are in an archive that is
+not unpacked), so the expected values here are restated from the loader's source: parity
+of this row is unpinned against the reference and pinned against that restatement only.
+"""
+import numpy as np
+import pytest
+
+from glb_scenes import quad, room_glb
+from glb_writer import FLOAT, U8, U16, U32, GlbBuilder, png_bytes, trs_matrix
+from raytracer_amd import capi
+from test_host_layer import decode_model, i32
+
+
+def load(path):
+    return capi.Scene("glb:" + str(path))
+
+
+def model_verts(sc, m=0):
+    d = decode_model(sc, m)
+    info = i32(sc.streams[3]).reshape(-1, 4)
+    end = info[m + 1][3] if m + 1 < sc.models_count else sc.streams[4].size
+    return d, sc.streams[4][d["vert_at"]: end].reshape(-1, 8)
+
+
+def tri_set(verts, ident):
+    """Triangles as a sorted list of rounded corner positions (independent of leaf order)."""
+    return sorted(tuple(np.round(verts[t[:3], :3].reshape(-1), 5)) for t in ident)
+
+
+def test_missing_or_malformed_file_yields_no_scene(tmp_path):
+    with pytest.raises(capi.RtError):
+        load(tmp_path / "absent.glb")
+    bad = tmp_path / "bad.glb"
+    bad.write_bytes(b"glTF" + b"\x02\0\0\0" + b"\x20\0\0\0" + b"\xff" * 20)
+    with pytest.raises(capi.RtError):
+        load(bad)
+    junk = tmp_path / "junk.glb"
+    junk.write_bytes(b"not a glb at all, just text")
+    with pytest.raises(capi.RtError):
+        load(junk)
+
+
+def test_node_transforms_and_index_types(tmp_path):
+    """world = parent * (T * R * S); positions transformed, normals by the inverse transpose;
+    u8/u16/u32 indices; a `matrix` node; a non-indexed primitive adds vertices but no triangles."""
+    b = GlbBuilder()
+    m = b.material(pbrMetallicRoughness={"baseColorFactor": [0.5, 0.5, 0.5, 1]})
+    rng = np.random.default_rng(1)
+    expect_pos, expect_nrm, expect_tris = [], [], []
+
+    def add(world, index_type, base, normals=True, indexed=True):
+        p = rng.uniform(-1, 1, (6, 3)).astype(np.float32)
+        n = rng.normal(size=(6, 3))
+        n = (n / np.linalg.norm(n, axis=1, keepdims=True)).astype(np.float32)
+        idx = np.array([0, 1, 2, 3, 4, 5, 0, 2, 4])
+        prim = b.primitive(p, idx if indexed else None, m, normals=n if normals else None, index_type=index_type)
+        expect_pos.append((world[:3, :3] @ p.T.astype(float)).T + world[:3, 3])
+        nm = np.linalg.inv(world[:3, :3]).T
+        nn = (nm @ (n if normals else np.tile([0, 1, 0], (6, 1))).T.astype(float)).T
+        expect_nrm.append(nn / np.linalg.norm(nn, axis=1, keepdims=True))
+        if indexed:
+            expect_tris.extend((idx.reshape(-1, 3) + base).tolist())
+        return prim
+
+    s, c = np.sin(0.4), np.cos(0.4)
+    parent = trs_matrix([0.5, -0.25, 2.0], [0, s, 0, c], [2, 1, 0.5])
+    child = trs_matrix([0, 1, 0], [s, 0, 0, c], [1, 3, 1])
+    mat = np.array([[0, -1, 0, 0.3], [1, 0, 0, 0.1], [0, 0, 2, -0.7], [0, 0, 0, 1]], float)
+    mesh_a = b.mesh([add(parent, U8, 0), add(parent, U16, 6, normals=False)])
+    mesh_b = b.mesh([add(parent @ child, U32, 12), add(parent @ child, U16, 18, indexed=False)])
+    mesh_c = b.mesh([add(mat, U16, 24)])
+    nb = b.node(mesh=mesh_b, translation=[0, 1, 0], rotation=[s, 0, 0, c], scale=[1, 3, 1])
+    b.node(mesh=mesh_a, children=[nb], root=True, translation=[0.5, -0.25, 2.0], rotation=[0, s, 0, c], scale=[2, 1, 0.5])
+    b.node(mesh=mesh_c, root=True, matrix=mat.T.reshape(-1).tolist())   # column-major
+    sc = load(b.write(tmp_path / "xf.glb"))
+
+    assert sc.models_count == 1 and sc.light_sources_count == 0
+    d, verts = model_verts(sc)
+    assert verts.shape[0] == 30 and d["idents"] == 12
+    assert np.allclose(verts[:, :3], np.concatenate(expect_pos), atol=2e-6)
+    assert np.allclose(verts[:, 3:6], np.concatenate(expect_nrm), atol=2e-6)
+    assert np.array_equal(verts[:, 6:8], np.zeros((30, 2), np.float32))      # no TEXCOORD_0
+    got = sorted(tuple(t) for t in d["ident"][:, :3].tolist())
+    assert got == sorted(tuple(t) for t in expect_tris)
+    assert (d["ident"][:, 3] == 1).all()                                     # scene material 0 is the default one
+
+
+@pytest.mark.parametrize("uv_type,stride,pad", [(FLOAT, None, 0), (FLOAT, 20, 4), (U8, 4, 0), (U16, None, 0), (U16, 8, 8)])
+def test_texcoord_formats_and_stride(tmp_path, uv_type, stride, pad):
+    b = GlbBuilder()
+    m = b.material()
+    p, n, _, i = quad([0, 0, 0], [1, 0, 0], [0, 1, 0])
+    uv = np.array([[0.0, 1.0], [0.2, 0.4], [0.6, 0.8], [1.0, 0.0]])
+    b.node(mesh=b.mesh([b.primitive(p, i, m, normals=n, uvs=uv, uv_type=uv_type, uv_stride=stride, uv_pad_front=pad)]), root=True)
+    _, verts = model_verts(load(b.write(tmp_path / "uv.glb")))
+    if uv_type == FLOAT:
+        expect = uv.astype(np.float32)
+    elif uv_type == U8:
+        expect = np.round(uv * 255).astype(np.float32) / np.float32(255)
+    else:
+        expect = np.round(uv * 65535).astype(np.float32) / np.float32(65535)
+    assert np.array_equal(verts[:, 6:8], expect)
+
+
+def test_materials_follow_the_reference_mapping(tmp_path):
+    b = GlbBuilder()
+    tex = [b.texture(png_bytes(np.full((2, 2, 3), 10 * k, np.uint8))) for k in range(6)]
+    b.material()                                                             # 0: all defaults
+    b.material(alphaMode="MASK",                                             # 1: cutoff default .5
+               pbrMetallicRoughness={"baseColorFactor": [0.1, 0.2, 0.3, 0.4], "metallicFactor": 0.25, "roughnessFactor": 0.75,
+                                     "baseColorTexture": {"index": tex[1]}, "metallicRoughnessTexture": {"index": tex[2]}},
+               normalTexture={"index": tex[0], "scale": 0.5}, occlusionTexture={"index": tex[5], "strength": 0.3},
+               emissiveTexture={"index": tex[3]}, emissiveFactor=[0.5, 0.25, 0.125])
+    b.material(alphaMode="BLEND", alphaCutoff=0.9,                           # 2: BLEND ignores the cutoff
+               extensions={"KHR_materials_volume": {"thicknessFactor": 0.6},
+                           "KHR_materials_transmission": {"transmissionFactor": 0.8, "transmissionTexture": {"index": tex[4]}},
+                           "KHR_materials_ior": {"ior": 1.33},
+                           "KHR_materials_emissive_strength": {"emissiveStrength": 0.0}})
+    b.material(alphaMode="MASK", alphaCutoff=0.3)                            # 3
+    prims = []
+    for k in range(4):
+        p, n, uv, i = quad([k, 0, 0], [0.5, 0, 0], [0, 0.5, 0])
+        prims.append(b.primitive(p, i, k, normals=n, uvs=uv))
+    p, n, uv, i = quad([9, 0, 0], [0.5, 0, 0], [0, 0.5, 0])
+    prims.append(b.primitive(p, i, None, normals=n))                         # no material -> model material 0
+    b.node(mesh=b.mesh(prims), root=True)
+    sc = load(b.write(tmp_path / "mat.glb"))
+
+    mats = sc.streams[2].reshape(-1, 23)
+    assert mats.shape[0] == 1 + 4
+    refs = i32(mats[:, :6])           # normal, baseColor, metallicRoughness, emissive, transmission, occlusion
+    f = mats[:, 6:]                   # emission rgb, strength, albedo rgb, subsurface, roughness, metallic, specular,
+    #                                   specularTint, transmission, ior, alphaCut, normalScale, occlusionStrength
+    header = 5 + 2 * 2 * 4            # every 2x2 image is decoded to RGBA
+    assert list(refs[1]) == [-1] * 6
+    assert np.allclose(f[1], [0, 0, 0, 1, 1, 1, 1, 0, 1, 1, 0.5, 0, 0, 1.5, 0, 1, 1])
+    assert list(refs[2]) == [tex[0] * header, tex[1] * header, tex[2] * header, tex[3] * header, -1, tex[5] * header]
+    assert np.allclose(f[2], [0.5, 0.25, 0.125, 1, 0.1, 0.2, 0.3, 0, 0.75, 0.25, 0.5, 0, 0, 1.5, 0.5, 0.5, 0.3])
+    assert list(refs[3]) == [-1, -1, -1, -1, tex[4] * header, -1]
+    assert np.allclose(f[3], [0, 0, 0, 0, 1, 1, 1, 0.6, 1, 1, 0.5, 0, 0.8, 1.33, 0, 1, 1])
+    assert np.isclose(f[4][14], 0.3)
+
+    d, verts = model_verts(sc)
+    by_x = {int(round(float(verts[t[0], 0]))): t for t in d["ident"]}
+    assert [int(by_x[k][3]) for k in (0, 1, 2, 3, 9)] == [1, 2, 3, 4, 1]
+    flags = {k: bool(by_x[k][4] != 0) for k in by_x}   # the flag word is a float 0/1; any non-zero bit pattern is true
+    assert flags == {0: False, 1: True, 2: False, 3: False, 9: False}        # a transmission texture alone does not count
+
+
+def test_emissive_primitives_become_the_leading_light_set(tmp_path):
+    b = GlbBuilder()
+    plain = b.material(pbrMetallicRoughness={"baseColorFactor": [0.7, 0.7, 0.7, 1]})
+    lamp = b.material(emissiveFactor=[1, 1, 1], extensions={"KHR_materials_emissive_strength": {"emissiveStrength": 4.0}})
+    dark = b.material(emissiveFactor=[0, 0, 0], extensions={"KHR_materials_emissive_strength": {"emissiveStrength": 4.0}})
+    glow = b.material(emissiveFactor=[1, 0, 0])   # emissive but no strength extension: stays ordinary geometry
+    quads = [(plain, 0), (lamp, 1), (dark, 2), (glow, 3), (lamp, 4)]
+    prims = []
+    for mat, x in quads:
+        p, n, uv, i = quad([x, 0, 0], [0.5, 0, 0], [0, 0.5, 0])
+        prims.append(b.primitive(p, i, mat, normals=n))
+    b.node(mesh=b.mesh(prims), root=True)
+    sc = load(b.write(tmp_path / "lights.glb"))
+    assert sc.light_sources_count == 1
+    d, verts = model_verts(sc)
+    assert d["lights"] == 4 and d["idents"] == 10
+    # light vertices are moved to the front: x = 1.. and 4.. first, then 0, 2, 3
+    assert [int(np.floor(x)) for x in verts[::4, 0]] == [1, 4, 0, 2, 3]
+    # the light-identifier copy keeps its model-local material index: only `identifiers` are
+    # re-based onto the scene's material list (src/RayScene.cpp:135-138)
+    assert d["light"][:, :3].max() < 8 and (d["light"][:, 3] == lamp).all()
+    assert tri_set(verts, d["light"]) == tri_set(verts, [t for t in d["ident"] if t[3] == 1 + lamp])
+    mats = sc.streams[2].reshape(-1, 23)
+    assert np.allclose(mats[1 + lamp][6:10], [1, 1, 1, 4]) and np.allclose(mats[1 + glow][6:10], [1, 0, 0, 1])
+
+
+@pytest.mark.parametrize("mode", ["RGBA", "RGB", "L", "LA", "P"])
+def test_png_textures_match_an_independent_decoder(tmp_path, mode):
+    from PIL import Image
+    import io
+    rng = np.random.default_rng(5)
+    w, h = 13, 7
+    if mode == "P":
+        img = Image.fromarray(rng.integers(0, 255, (h, w, 3), dtype=np.uint8), "RGB").quantize(17)
+    else:
+        ch = {"RGBA": 4, "RGB": 3, "L": 1, "LA": 2}[mode]
+        arr = rng.integers(0, 255, (h, w, ch), dtype=np.uint8)
+        arr[2:5] = np.arange(w)[None, :, None] * 9 + np.arange(3)[:, None, None]   # smooth rows pick other PNG filters
+        img = Image.fromarray(arr[..., 0] if ch == 1 else arr, mode)
+    buf = io.BytesIO()
+    img.save(buf, format="PNG", optimize=True)
+    expect = np.asarray(img.convert("RGBA"), np.uint8).astype(np.float32) / np.float32(255)
+
+    b = GlbBuilder()
+    t = b.texture(buf.getvalue(), wrap_s=33648, with_sampler=True)
+    m = b.material(pbrMetallicRoughness={"baseColorTexture": {"index": t}})
+    p, n, uv, i = quad([0, 0, 0], [1, 0, 0], [0, 1, 0])
+    b.node(mesh=b.mesh([b.primitive(p, i, m, normals=n, uvs=uv)]), root=True)
+    sc = load(b.write(tmp_path / "tex.glb"))
+    tex = sc.streams[5]
+    assert list(i32(tex[:5])) == [w, h, 4, 33648, 10497]
+    assert np.array_equal(tex[5:].reshape(h, w, 4), expect)
+
+
+def test_room_scene_has_the_expected_structure(tmp_path):
+    sc = load(room_glb(tmp_path / "room.glb", nu=12, nv=6))
+    assert sc.models_count == 1 and sc.light_sources_count == 1 and sc.object_count == 0
+    st = sc.model_stats(0)
+    assert st["triangles"] == 10 + 2 + 2 * 12 * 6 + 2 and st["light_triangles"] == 2 and st["valid"] == 1
+    d, verts = model_verts(sc)
+    # the panel (child of the room node, translated by +1 in y) hangs just under the ceiling
+    assert np.allclose(verts[:4, 1], 1.999, atol=1e-6)
+    # every position lies in the room's bounds
+    assert verts[:, 0].min() >= -1 - 1e-6 and verts[:, 0].max() <= 1 + 1e-6 and verts[:, 1].min() >= -1e-6 and verts[:, 1].max() <= 2 + 1e-6
+
+
+def test_two_files_make_two_models(tmp_path):
+    a = room_glb(tmp_path / "a.glb", nu=8, nv=4)
+    b = GlbBuilder()
+    m = b.material(pbrMetallicRoughness={"baseColorFactor": [0.2, 0.3, 0.9, 1], "metallicFactor": 0.0})
+    p, n, uv, i = quad([-0.3, 0.01, -0.6], [0.6, 0, 0], [0, 0.4, 0.2])
+    b.node(mesh=b.mesh([b.primitive(p, i, m, normals=n)]), root=True)
+    sc = capi.Scene("glb:" + a + ";" + b.write(tmp_path / "b.glb"))
+    assert sc.models_count == 2 and sc.light_sources_count == 1
+    mats = sc.streams[2].reshape(-1, 23)
+    assert mats.shape[0] == 1 + 6 + 1
+    d1 = decode_model(sc, 1)
+    assert (d1["ident"][:, 3] == 7).all()      # second file's material 0 -> scene material 7
