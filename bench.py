@@ -53,6 +53,7 @@ def main():
     import torch.distributed as dist
 
     from raytracer_amd import capi
+    from raytracer_amd.sharding import reduce_accum
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -90,7 +91,11 @@ def main():
             be.render(first_frame=1 + k * args.spp * world + rank, n_frames=args.spp, stride=world)
         be.sync()
         if distributed:
-            dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
+            # Rank 0 keeps the running total; the others restart from zero so the next merge adds
+            # only new frames.  The merge runs on torch's stream: finish it before the backend's
+            # stream writes into the buffer again.
+            reduce_accum(accum, dist, dst=0)
+            torch.cuda.current_stream().synchronize()
 
     def barrier():
         if distributed:
@@ -110,7 +115,7 @@ def main():
     accum.zero_()
 
     for k in range(args.warmup):
-        step(-1 - k if False else k)
+        step(k)
     be.reset_accum()
     accum.zero_()
     be.reset_stats()

@@ -19,7 +19,9 @@ typedef struct rth_engine rth_engine;
 
 /* Builds one of the named scenes into a host-only RayScene (streams kept on the
  * host) and submits it.  Names: "cornell_quads", "roughness_demo", "three_color",
- * "cornell_knot", "knot_glass", "prism", "textured_room", "mixed".
+ * "cornell_knot", "knot_glass", "prism", "textured_room", "mixed", and
+ * "glb:<a.glb>[;<b.glb>...]" = one RayScene::addModel(path) per binary glTF file under a black sky
+ * (NULL if a file cannot be loaded).
  * iparams: [0]=knot nu, [1]=knot nv, [2]=texture size, [3]=seed (0 = defaults). */
 rth_scene *rth_scene_build(const char *name, const int32_t *iparams, int n_iparams);
 void rth_scene_free(rth_scene *scene);
@@ -43,6 +45,12 @@ int rth_engine_render(rth_engine *engine, int frames);
 /* Progressive mean, width*height*4 floats; returns frames rendered so far or < 0. */
 int rth_engine_frame(rth_engine *engine, float *rgba, size_t floats);
 void rth_engine_free(rth_engine *engine);
+
+/* File output of a frame (no reference counterpart: the reference only draws to its window).
+ * rgba8 as rt_display_rgba8 returns it; rgba as rt_readback returns it, scaled by `scale`
+ * (1/frames gives the progressive mean).  Row 0 = bottom row in both.  0 or RT_ERR_INVALID. */
+int rth_write_png(const char *path, const uint8_t *rgba8, int width, int height);
+int rth_write_pfm(const char *path, const float *rgba, int width, int height, float scale);
 
 #ifdef __cplusplus
 }

@@ -26,7 +26,7 @@ HIP_SYMBOLS = [
 HOST_SYMBOLS = [
     "rth_scene_build", "rth_scene_free", "rth_scene_counts", "rth_scene_sky", "rth_scene_stream",
     "rth_scene_model_stats", "rth_camera_make", "rth_engine_create", "rth_engine_render", "rth_engine_frame",
-    "rth_engine_free",
+    "rth_engine_free", "rth_write_png", "rth_write_pfm",
 ]
 
 
@@ -115,6 +115,22 @@ host.rth_engine_render.argtypes = [_vp, _i]
 host.rth_engine_frame.argtypes = [_vp, _vp, _sz]
 host.rth_engine_free.argtypes = [_vp]
 host.rth_engine_free.restype = None
+host.rth_write_png.argtypes = [C.c_char_p, _vp, _i, _i]
+host.rth_write_pfm.argtypes = [C.c_char_p, _vp, _i, _i, _f]
+
+
+def write_png(path, rgba8):
+    """Writes an (H, W, 4) uint8 frame (row 0 = bottom row, as Backend.display_rgba8 returns it)."""
+    a = np.ascontiguousarray(rgba8, dtype=np.uint8)
+    if a.ndim != 3 or a.shape[2] != 4 or host.rth_write_png(str(path).encode(), a.ctypes.data_as(_vp), a.shape[1], a.shape[0]) != 0:
+        raise RtError(f"cannot write {path}")
+
+
+def write_pfm(path, rgba, scale=1.0):
+    """Writes the colour channels of an (H, W, 4) float32 frame (row 0 = bottom row) times `scale`."""
+    a = np.ascontiguousarray(rgba, dtype=np.float32)
+    if a.ndim != 3 or a.shape[2] != 4 or host.rth_write_pfm(str(path).encode(), a.ctypes.data_as(_vp), a.shape[1], a.shape[0], scale) != 0:
+        raise RtError(f"cannot write {path}")
 
 
 def _iparams(params):

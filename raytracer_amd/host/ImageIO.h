@@ -1,0 +1,20 @@
+// Image output for rendered frames: 8-bit PNG of the display pass and float PFM of the
+// progressive mean.  The reference shows frames only in its window (src/main.cpp:36-69) and
+// has no file output beyond the loader's debug BMP dump (src/MeshData.cpp:330-415); these
+// writers give a headless render somewhere to go.
+#pragma once
+
+#include <cstdint>
+#include <string>
+
+namespace imageio {
+
+// rgba8: width*height*4 bytes, row 0 = bottom row (the frame layout of the backend); the file
+// stores rows top-down.  Returns false if the file cannot be written.
+bool WritePNG(const std::string &path, const uint8_t *rgba8, int width, int height);
+
+// rgba: width*height*4 floats, row 0 = bottom row (PFM's own order); writes the three colour
+// channels scaled by `scale` (1/frames turns a sum buffer into the mean) as little-endian PFM.
+bool WritePFM(const std::string &path, const float *rgba, int width, int height, float scale);
+
+}  // namespace imageio

@@ -2,6 +2,7 @@
 // by tests, bench and the smoke check.
 #include "rt_host.h"
 
+#include "ImageIO.h"
 #include "ProceduralMesh.h"
 #include "RayEngine.h"
 #include "RaySceneBuilder.h"
@@ -265,5 +266,15 @@ int rth_engine_frame(rth_engine *e, float *rgba, size_t floats) {
 }
 
 void rth_engine_free(rth_engine *e) { delete e; }
+
+int rth_write_png(const char *path, const uint8_t *rgba8, int width, int height) {
+    if (path == nullptr) return RT_ERR_INVALID;
+    return imageio::WritePNG(path, rgba8, width, height) ? RT_OK : RT_ERR_INVALID;
+}
+
+int rth_write_pfm(const char *path, const float *rgba, int width, int height, float scale) {
+    if (path == nullptr) return RT_ERR_INVALID;
+    return imageio::WritePFM(path, rgba, width, height, scale) ? RT_OK : RT_ERR_INVALID;
+}
 
 }  // extern "C"

@@ -27,8 +27,17 @@ def sample_split(total_frames: int, world: int, rank: int, base_frame: int = 1) 
     return FrameShard(base_frame + rank, n, world)
 
 
-def reduce_accum(accum, dist=None, dst=0):
-    """Sums the per-rank accumulation tensors onto `dst` in place (RCCL on GPU tensors, gloo on CPU)."""
+def reduce_accum(accum, dist=None, dst=0, clear_others=True):
+    """Sums the per-rank accumulation tensors onto `dst` in place (RCCL on GPU tensors, gloo on CPU).
+
+    With clear_others the other ranks zero their tensor afterwards: `dst` then holds the running
+    total of everything rendered so far and the others only what they rendered since the last
+    merge, so the call can be repeated after every batch of frames without double counting.
+    The caller must not let its renderer write into `accum` before the queued reduce/zero have
+    finished (on a GPU: synchronise the stream they were issued on first).
+    """
     if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
         dist.reduce(accum, dst=dst, op=dist.ReduceOp.SUM)
+        if clear_others and dist.get_rank() != dst:
+            accum.zero_()
     return accum

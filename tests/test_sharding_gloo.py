@@ -42,10 +42,17 @@ def _worker(rank, world, port, total_frames, out_path):
 
     scene = capi.Scene("cornell_knot", nu=32, nv=8)
     cam = capi.make_camera(width=24, height=16, bounces=3, ray_per_pixel=1)
-    sh = sample_split(total_frames, world, rank)
-    rgba, _ = OracleScene(scene).render(cam, 0, sh.first_frame, sh.n_frames, sh.stride, threads=2)
-    accum = torch.from_numpy(rgba)
-    reduce_accum(accum, dist, dst=0)
+    # Two batches, merged after each one the way bench.py's steps do: rank 0 keeps the running
+    # total, the other ranks restart from zero after every merge.
+    accum = None
+    orc = OracleScene(scene)
+    for batch in range(2):
+        sh = sample_split(total_frames, world, rank, base_frame=1 + batch * total_frames)
+        rgba, _ = orc.render(cam, 0, sh.first_frame, sh.n_frames, sh.stride, threads=2)
+        accum = torch.from_numpy(rgba) if accum is None else accum + torch.from_numpy(rgba)
+        reduce_accum(accum, dist, dst=0)
+        if rank != 0:
+            assert float(accum.abs().sum()) == 0.0
     if rank == 0:
         np.save(out_path, accum.numpy())
     dist.barrier()
@@ -66,6 +73,6 @@ def test_two_rank_reduce_equals_single_rank(tmp_path):
 
     scene = capi.Scene("cornell_knot", nu=32, nv=8)
     cam = capi.make_camera(width=24, height=16, bounces=3, ray_per_pixel=1)
-    want, _ = OracleScene(scene).render(cam, 0, 1, total, 1, threads=2)
+    want, _ = OracleScene(scene).render(cam, 0, 1, 2 * total, 1, threads=2)
     assert np.array_equal(got[..., 3], want[..., 3])                 # every frame counted once
     assert np.allclose(got[..., :3], want[..., :3], rtol=1e-6, atol=1e-7)   # only the addition order differs
