@@ -102,10 +102,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # Per-ray visit counts of this workload (one counted frame), for the algorithmic byte model.
+    # Per-ray visit counts of this workload for the algorithmic byte model: one whole step with the
+    # counters on (untimed; it also sizes the path buffers, so no allocation lands in the timed region).
     be.set_counters(True)
     be.reset_stats()
-    be.render(first_frame=1, n_frames=1, stride=1)
+    be.render(first_frame=1, n_frames=args.spp, stride=1)
     cst = be.stats()
     be.set_counters(False)
     nodes_per_ray = cst["node_visits"] / max(cst["rays"], 1)

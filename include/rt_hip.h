@@ -151,8 +151,12 @@ int rt_set_counters(rt_ctx *ctx, int enabled);
  *                            (the visit counters then equal the reference algorithm's).
  *   RT_OPT_REFILL_LANES      idle lanes that trigger a refill in the traversal kernel (1..64)
  *   RT_OPT_INNER_SHARE       share (x/64) of active lanes on inner nodes that selects the
- *                            inner-node phase (1..64) */
-enum { RT_OPT_SHADOW_EARLY_OUT = 1, RT_OPT_REFILL_LANES = 2, RT_OPT_INNER_SHARE = 3 };
+ *                            inner-node phase (1..64)
+ *   RT_OPT_MAX_PATHS         ceiling of paths in flight per batch (whole sample planes, at least
+ *                            one; about 190 bytes of device memory per path).  Default 128 Mi,
+ *                            further limited to half of the free device memory.  A render call
+ *                            that needs fewer paths allocates only what it needs. */
+enum { RT_OPT_SHADOW_EARLY_OUT = 1, RT_OPT_REFILL_LANES = 2, RT_OPT_INNER_SHARE = 3, RT_OPT_MAX_PATHS = 4 };
 int rt_set_option(rt_ctx *ctx, int option, int value);
 
 const char *rt_strerror(int status);

@@ -46,7 +46,10 @@ namespace {
 constexpr int kStackDepth = 32;      // int stack[32], src/RayScene.cpp:682
 constexpr int kBlock = 256;
 constexpr int kMaxBounces = 62;      // stages kept on the device
-constexpr uint32_t kDefaultMaxPaths = 8u << 20;
+// Default ceiling of paths in flight per batch (~190 B of device memory each).  Every kernel of
+// a batch ends with a drain tail in which most of the chip idles, so few large batches beat many
+// small ones: the default bench step (1920x1080 x 64 sample planes) fits in one batch.
+constexpr uint32_t kDefaultMaxPaths = 128u << 20;
 constexpr float kNeverStop = -1e30f;  // RayRec::pad1 of rays that must find their closest hit
 
 // Per-frame uniforms plus values derived from them once on the host.
@@ -1310,10 +1313,20 @@ int repackScene(rt_ctx *ctx, std::vector<PackedNode> &nodes, std::vector<PackedT
     return RT_OK;
 }
 
-int ensurePathBuffers(rt_ctx *ctx) {
-    const uint32_t npt = ctx->fp.npt;
-    uint32_t want = std::max(npt, (ctx->maxPaths / std::max(npt, 1u)) * npt);
-    if (want == ctx->P && ctx->pb.rays != nullptr) return RT_OK;
+// Makes room for min(wantedPaths, ceiling) paths, whole sample planes, at least one.  Grows only.
+int ensurePathBuffers(rt_ctx *ctx, uint64_t wantedPaths) {
+    const uint32_t npt = std::max(ctx->fp.npt, 1u);
+    uint64_t ceiling = ctx->maxPaths;
+    size_t freeBytes = 0, totalBytes = 0;
+    if (hipMemGetInfo(&freeBytes, &totalBytes) == hipSuccess) {
+        // Path state may take up to half of what is free now (plus what it already holds).
+        const uint64_t perPath = 2 * sizeof(RayRec) + 2 * sizeof(HitRec) + 5 * sizeof(float4) + 3 * sizeof(uint32_t) + 4;
+        ceiling = std::min<uint64_t>(ceiling, (freeBytes / 2 + (uint64_t)ctx->P * perPath) / perPath);
+    }
+    const uint64_t planes = std::max<uint64_t>(1, std::min<uint64_t>(ceiling / npt, (wantedPaths + npt - 1) / npt));
+    if (planes * npt > 0x7fffffffull) return RT_ERR_INVALID;
+    const uint32_t want = (uint32_t)(planes * npt);
+    if (ctx->pb.rays != nullptr && ctx->P >= want) return RT_OK;
     int rc;
     if ((rc = devAlloc(ctx, &ctx->pb.rays, (size_t)want * 2)) != RT_OK) return rc;
     if ((rc = devAlloc(ctx, &ctx->pb.hits, (size_t)want * 2)) != RT_OK) return rc;
@@ -1582,16 +1595,17 @@ int rt_render(rt_ctx *ctx, uint32_t first_frame, uint32_t n_frames, uint32_t fra
     if (!ctx->committed || !ctx->frameSet || ctx->dAccum == nullptr) return RT_ERR_STATE;
     if (n_frames == 0) return RT_OK;
     RT_HIP(hipSetDevice(ctx->device));
-    int rc = ensurePathBuffers(ctx);
+    const FrameParams &fp = ctx->fp;
+    const uint64_t totalPlanes = (uint64_t)n_frames * fp.S;
+    if (totalPlanes > 0xffffffffull) return RT_ERR_INVALID;
+    int rc = ensurePathBuffers(ctx, totalPlanes * fp.npt);
     if (rc != RT_OK) return rc;
 
     hipEvent_t e0 = takeEvent(ctx), e1 = takeEvent(ctx);
     if (e0) hipEventRecord(e0, ctx->stream);
 
-    const FrameParams &fp = ctx->fp;
-    const uint64_t totalPlanes = (uint64_t)n_frames * fp.S;
-    if (totalPlanes > 0xffffffffull) return RT_ERR_INVALID;
-    const uint32_t planesPerBatch = std::max(1u, ctx->P / fp.npt);
+    // Batches never exceed the current ceiling even when a larger buffer is already held.
+    const uint32_t planesPerBatch = std::max(1u, std::min(ctx->P, std::max(ctx->maxPaths, fp.npt)) / fp.npt);
     for (uint64_t g = 0; g < totalPlanes; g += planesPerBatch) {
         Batch bt;
         bt.g0 = (uint32_t)g;
@@ -1705,7 +1719,7 @@ int rt_trace_primary(rt_ctx *ctx, uint32_t frame, int32_t *model, int32_t *ident
     if (ctx == nullptr || model == nullptr || ident == nullptr || t == nullptr || u == nullptr || v == nullptr) return RT_ERR_INVALID;
     if (!ctx->committed || !ctx->frameSet) return RT_ERR_STATE;
     RT_HIP(hipSetDevice(ctx->device));
-    int rc = ensurePathBuffers(ctx);
+    int rc = ensurePathBuffers(ctx, ctx->fp.npt);
     if (rc != RT_OK) return rc;
     const FrameParams &fp = ctx->fp;
     Batch bt;
@@ -1802,6 +1816,10 @@ int rt_set_option(rt_ctx *ctx, int option, int value) {
         case RT_OPT_INNER_SHARE:
             if (value < 1 || value > 64) return RT_ERR_INVALID;
             ctx->innerShare = value;
+            return RT_OK;
+        case RT_OPT_MAX_PATHS:
+            if (value < 1) return RT_ERR_INVALID;
+            ctx->maxPaths = (uint32_t)value;
             return RT_OK;
         default:
             return RT_ERR_INVALID;

@@ -108,6 +108,27 @@ def test_frame_stride_and_batching(backend):
     assert np.array_equal(three, want)
 
 
+def test_batch_capacity_does_not_change_the_image(backend):
+    """27 sample planes rendered as one batch, as batches of two planes and plane by plane."""
+    W, H = 40, 40
+    scene, cam = _setup(backend, "mixed", dict(nu=48, nv=8), W, H, 3, 9, capi.RT_TYPE_RGB)
+    images = []
+    try:
+        for cap in (1 << 27, 2 * 40 * 40, 1):
+            backend.set_option(capi.RT_OPT_MAX_PATHS, cap)
+            backend.reset_accum()
+            backend.reset_stats()
+            backend.render(first_frame=1, n_frames=3, stride=1)
+            images.append(backend.readback()[0])
+            launches = backend.stats()["trace_launches"]
+            assert launches == {1 << 27: 1, 2 * 40 * 40: 14, 1: 27}[cap] * 5   # (bounces + 2) traversal launches per batch
+    finally:
+        backend.set_option(capi.RT_OPT_MAX_PATHS, 1 << 27)
+    want, _ = OracleScene(scene).render(cam, 0, 1, 3, 1)
+    for img in images:
+        assert np.array_equal(img, want)
+
+
 def test_shadow_early_out_does_not_change_the_image(backend):
     W, H = 64, 48
     scene, cam = _setup(backend, "cornell_knot", dict(nu=128, nv=24), W, H, 4, 4, capi.RT_TYPE_RGB)
