@@ -123,6 +123,17 @@ int rt_bind_accum(rt_ctx *ctx, void *dev_ptr, size_t floats);
 /* Adds `frames` to the frame count after an external reduce merged other ranks' sums. */
 int rt_add_frames(rt_ctx *ctx, uint32_t frames);
 
+/* Multi-GPU merge for callers without torch.distributed (no reference counterpart: the reference
+ * is single-GPU).  One context per process per GPU.  Rank 0 obtains a 128-byte id with
+ * rt_comm_unique_id and hands it to the other ranks by its own means; every rank calls
+ * rt_comm_init(ctx, rank, world, id, 128) (collective).  rt_reduce (collective) sums the ranks'
+ * sum buffers onto `root` with one RCCL reduce on the context's stream, adds up the frame counts,
+ * and clears the other ranks' buffers so that a later merge adds only new frames.  It blocks until
+ * done.  RCCL (librccl.so.1) is loaded on first use; RT_ERR_STATE if it cannot be. */
+int rt_comm_unique_id(void *id, size_t bytes);
+int rt_comm_init(rt_ctx *ctx, int rank, int world, const void *id, size_t bytes);
+int rt_reduce(rt_ctx *ctx, int root);
+
 /* Tile-split sharding (no reference counterpart): the context renders only the 8x8
  * pixel tiles whose row-major index i has i % stride == offset; other pixels of its
  * sum buffer stay untouched (zero after rt_resize / rt_reset_accum), so the shards'

@@ -21,6 +21,7 @@ HIP_SYMBOLS = [
     "rt_create", "rt_destroy", "rt_upload", "rt_commit_scene", "rt_resize", "rt_set_frame", "rt_render",
     "rt_reset_accum", "rt_sync", "rt_readback", "rt_display_rgba8", "rt_restore_accum", "rt_accum_device_ptr", "rt_bind_accum", "rt_add_frames",
     "rt_trace_primary", "rt_get_stats", "rt_reset_stats", "rt_set_counters", "rt_set_option", "rt_set_tile_shard", "rt_strerror", "rt_last_hip_error",
+    "rt_comm_unique_id", "rt_comm_init", "rt_reduce",
 ]
 # Every symbol include/rt_host.h declares.
 HOST_SYMBOLS = [
@@ -95,6 +96,9 @@ hip.rt_reset_stats.argtypes = [_vp]
 hip.rt_set_counters.argtypes = [_vp, _i]
 hip.rt_set_option.argtypes = [_vp, _i, _i]
 hip.rt_set_tile_shard.argtypes = [_vp, _u32, _u32]
+hip.rt_comm_unique_id.argtypes = [_vp, _sz]
+hip.rt_comm_init.argtypes = [_vp, _i, _i, _vp, _sz]
+hip.rt_reduce.argtypes = [_vp, _i]
 hip.rt_strerror.argtypes = [_i]
 hip.rt_strerror.restype = C.c_char_p
 hip.rt_last_hip_error.argtypes = [_vp]
@@ -117,6 +121,14 @@ host.rth_engine_free.argtypes = [_vp]
 host.rth_engine_free.restype = None
 host.rth_write_png.argtypes = [C.c_char_p, _vp, _i, _i]
 host.rth_write_pfm.argtypes = [C.c_char_p, _vp, _i, _i, _f]
+
+
+def comm_unique_id():
+    buf = C.create_string_buffer(128)
+    rc = hip.rt_comm_unique_id(buf, 128)
+    if rc != 0:
+        raise RtError(hip.rt_strerror(rc).decode())
+    return buf.raw
 
 
 def write_png(path, rgba8):
@@ -267,6 +279,14 @@ class Backend:
 
     def set_tile_shard(self, offset, stride):
         self._check(hip.rt_set_tile_shard(self._ctx, offset, stride))
+
+    def comm_init(self, rank, world, unique_id):
+        """Joins an RCCL communicator of `world` contexts (collective); `unique_id` from comm_unique_id() on rank 0."""
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        self._check(hip.rt_comm_init(self._ctx, rank, world, buf, 128))
+
+    def reduce(self, root=0):
+        self._check(hip.rt_reduce(self._ctx, root))
 
     def set_option(self, option, value):
         self._check(hip.rt_set_option(self._ctx, option, int(value)))

@@ -24,6 +24,8 @@
 // Build with -ffp-contract=off (see rt_math.h).
 
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cstdio>
@@ -1095,6 +1097,11 @@ struct rt_ctx {
     int refillLanes = 32;   // idle lanes that trigger a refill for stages > 0
     int innerShare = 48;    // inner phase runs while >= innerShare/64 of the active lanes sit on inner nodes
 
+    // RCCL communicator of rt_comm_init (library loaded on first use), one rank per context.
+    void *comm = nullptr;
+    int commRank = 0, commWorld = 1;
+    unsigned long long *dFrameCount = nullptr;
+
     std::vector<std::pair<hipEvent_t, hipEvent_t>> traceEvents, renderEvents;
     std::vector<hipEvent_t> eventPool;
     double traceMs = 0.0, totalMs = 0.0;
@@ -1411,9 +1418,117 @@ int runBatch(rt_ctx *ctx, const Batch &bt) {
     return RT_OK;
 }
 
+// RCCL is bound at run time so that the library has no link dependency on it: only a caller
+// that shards over several GPUs from C/C++ (no torch.distributed around) ever loads it.
+struct Rccl {
+    void *lib = nullptr;
+    ncclResult_t (*getUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*commInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*commDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*reduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*allReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*errorString)(ncclResult_t) = nullptr;
+};
+
+Rccl *rccl() {
+    static Rccl api;
+    static bool tried = false;
+    if (!tried) {
+        tried = true;
+        void *lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (lib == nullptr) lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+        if (lib != nullptr) {
+            api.getUniqueId = reinterpret_cast<decltype(api.getUniqueId)>(dlsym(lib, "ncclGetUniqueId"));
+            api.commInitRank = reinterpret_cast<decltype(api.commInitRank)>(dlsym(lib, "ncclCommInitRank"));
+            api.commDestroy = reinterpret_cast<decltype(api.commDestroy)>(dlsym(lib, "ncclCommDestroy"));
+            api.reduce = reinterpret_cast<decltype(api.reduce)>(dlsym(lib, "ncclReduce"));
+            api.allReduce = reinterpret_cast<decltype(api.allReduce)>(dlsym(lib, "ncclAllReduce"));
+            api.errorString = reinterpret_cast<decltype(api.errorString)>(dlsym(lib, "ncclGetErrorString"));
+            if (api.getUniqueId && api.commInitRank && api.commDestroy && api.reduce && api.allReduce && api.errorString) api.lib = lib;
+        }
+    }
+    return api.lib != nullptr ? &api : nullptr;
+}
+
+#define RT_NCCL(ctx, api, call)                                                               \
+    do {                                                                                      \
+        ncclResult_t r_ = (call);                                                             \
+        if (r_ != ncclSuccess) {                                                              \
+            (ctx)->hipError = std::string(#call) + ": " + (api)->errorString(r_);             \
+            return RT_ERR_HIP;                                                                \
+        }                                                                                     \
+    } while (0)
+
+void closeComm(rt_ctx *ctx) {
+    if (ctx->comm != nullptr) {
+        if (Rccl *api = rccl()) api->commDestroy(static_cast<ncclComm_t>(ctx->comm));
+        ctx->comm = nullptr;
+    }
+    if (ctx->dFrameCount != nullptr) {
+        hipFree(ctx->dFrameCount);
+        ctx->dFrameCount = nullptr;
+    }
+    ctx->commRank = 0;
+    ctx->commWorld = 1;
+}
+
 }  // namespace
 
 extern "C" {
+
+int rt_comm_unique_id(void *id, size_t bytes) {
+    if (id == nullptr || bytes != sizeof(ncclUniqueId)) return RT_ERR_INVALID;
+    Rccl *api = rccl();
+    if (api == nullptr) return RT_ERR_STATE;
+    ncclUniqueId uid;
+    if (api->getUniqueId(&uid) != ncclSuccess) return RT_ERR_HIP;
+    std::memcpy(id, &uid, sizeof uid);
+    return RT_OK;
+}
+
+int rt_comm_init(rt_ctx *ctx, int rank, int world, const void *id, size_t bytes) {
+    if (ctx == nullptr || id == nullptr || bytes != sizeof(ncclUniqueId) || world < 1 || rank < 0 || rank >= world) return RT_ERR_INVALID;
+    Rccl *api = rccl();
+    if (api == nullptr) {
+        ctx->hipError = "rt_comm_init: librccl.so.1 could not be loaded";
+        return RT_ERR_STATE;
+    }
+    RT_HIP(hipSetDevice(ctx->device));
+    closeComm(ctx);
+    ncclUniqueId uid;
+    std::memcpy(&uid, id, sizeof uid);
+    ncclComm_t comm = nullptr;
+    RT_NCCL(ctx, api, api->commInitRank(&comm, world, uid, rank));
+    ctx->comm = comm;
+    ctx->commRank = rank;
+    ctx->commWorld = world;
+    RT_HIP(hipMalloc(reinterpret_cast<void **>(&ctx->dFrameCount), sizeof(unsigned long long)));
+    return RT_OK;
+}
+
+int rt_reduce(rt_ctx *ctx, int root) {
+    if (ctx == nullptr) return RT_ERR_INVALID;
+    if (ctx->comm == nullptr || ctx->dAccum == nullptr) return RT_ERR_STATE;
+    if (root < 0 || root >= ctx->commWorld) return RT_ERR_INVALID;
+    Rccl *api = rccl();
+    if (api == nullptr) return RT_ERR_STATE;
+    RT_HIP(hipSetDevice(ctx->device));
+    ncclComm_t comm = static_cast<ncclComm_t>(ctx->comm);
+    const size_t floats = (size_t)ctx->W * ctx->H * 4;
+    unsigned long long frames = ctx->framesAccum;
+    RT_HIP(hipMemcpyAsync(ctx->dFrameCount, &frames, sizeof frames, hipMemcpyHostToDevice, ctx->stream));
+    // Both collectives are queued on the context's stream, behind the render work already there.
+    RT_NCCL(ctx, api, api->reduce(ctx->dAccum, ctx->dAccum, floats, ncclFloat, ncclSum, root, comm, ctx->stream));
+    RT_NCCL(ctx, api, api->allReduce(ctx->dFrameCount, ctx->dFrameCount, 1, ncclUint64, ncclSum, comm, ctx->stream));
+    RT_HIP(hipMemcpyAsync(&frames, ctx->dFrameCount, sizeof frames, hipMemcpyDeviceToHost, ctx->stream));
+    if (ctx->commRank != root) RT_HIP(hipMemsetAsync(ctx->dAccum, 0, floats * sizeof(float), ctx->stream));
+    RT_HIP(hipStreamSynchronize(ctx->stream));
+    drainEvents(ctx);
+    // The root now holds every rank's frames; the others restart from zero, so that the
+    // next merge adds only what was rendered since this one.
+    ctx->framesAccum = ctx->commRank == root ? (uint32_t)frames : 0u;
+    return RT_OK;
+}
 
 int rt_create(rt_ctx **out, int device) {
     if (out == nullptr) return RT_ERR_INVALID;
@@ -1456,6 +1571,7 @@ void rt_destroy(rt_ctx *ctx) {
                      ctx->pb.qExt[0], ctx->pb.qExt[1], ctx->pb.qShadow, ctx->pb.stages, ctx->pb.counters};
     for (void *p : owned) if (p) hipFree(p);
     drainEvents(ctx);
+    closeComm(ctx);
     for (hipEvent_t e : ctx->eventPool) hipEventDestroy(e);
     hipStreamDestroy(ctx->stream);
     delete ctx;

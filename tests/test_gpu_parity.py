@@ -348,3 +348,22 @@ def test_glb_loaded_scene_ids_and_radiance(backend, tmp_path, rtype):
     want, _ = OracleScene(scene).render(cam, rtype, 1, frames, 1)
     assert n == frames and np.array_equal(got, want)
     assert got[..., :3].mean() > 0.01                    # lit by the glTF light set
+
+
+def test_rccl_merge_entry_point_single_rank(backend):
+    """rt_comm_init / rt_reduce through the C ABI with a world of one: the merge must leave the
+    root's image and frame count as they are (ranks > 1 need one GPU each and are exercised by
+    the multi-GPU bench; the sharding arithmetic is covered on CPU with gloo)."""
+    W, H = 48, 32
+    scene, cam = _setup(backend, "mixed", dict(nu=48, nv=8), W, H, 3, 1, capi.RT_TYPE_RGB)
+    backend.render(first_frame=1, n_frames=2, stride=1)
+    before, n0 = backend.readback()
+    backend.comm_init(0, 1, capi.comm_unique_id())
+    backend.reduce(root=0)
+    after, n1 = backend.readback()
+    assert n0 == n1 == 2 and np.array_equal(before, after)
+    backend.render(first_frame=3, n_frames=1, stride=1)
+    backend.reduce(root=0)
+    total, n2 = backend.readback()
+    want, _ = OracleScene(scene).render(cam, 0, 1, 3, 1)
+    assert n2 == 3 and np.array_equal(total, want)
