@@ -624,7 +624,10 @@ __global__ __launch_bounds__(kBlock) void k_connect(SceneView sc, Batch bt, Path
 }
 
 // One bounce of traceColor (src/RayTracer.cpp:333-538) for every path in the stage's queue.
-__global__ __launch_bounds__(kBlock) void k_shade_rgb(SceneView sc, FrameParams fp, Batch bt, PathBuffers pb, int stage, int countOn) {
+#ifndef RT_SHADE_BLOCKS
+#define RT_SHADE_BLOCKS 4
+#endif
+__global__ __launch_bounds__(kBlock, RT_SHADE_BLOCKS) void k_shade_rgb(SceneView sc, FrameParams fp, Batch bt, PathBuffers pb, int stage, int countOn) {
     const uint32_t sub = blockIdx.x % kSubQueues;
     const uint32_t n = pb.stages[stage].ext[sub].count;
     const uint32_t *qIn = pb.qExt[stage & 1] + (size_t)sub * pb.subCap;
@@ -1320,20 +1323,12 @@ int repackScene(rt_ctx *ctx, std::vector<PackedNode> &nodes, std::vector<PackedT
     return RT_OK;
 }
 
-// Makes room for min(wantedPaths, ceiling) paths, whole sample planes, at least one.  Grows only.
-int ensurePathBuffers(rt_ctx *ctx, uint64_t wantedPaths) {
-    const uint32_t npt = std::max(ctx->fp.npt, 1u);
-    uint64_t ceiling = ctx->maxPaths;
-    size_t freeBytes = 0, totalBytes = 0;
-    if (hipMemGetInfo(&freeBytes, &totalBytes) == hipSuccess) {
-        // Path state may take up to half of what is free now (plus what it already holds).
-        const uint64_t perPath = 2 * sizeof(RayRec) + 2 * sizeof(HitRec) + 5 * sizeof(float4) + 3 * sizeof(uint32_t) + 4;
-        ceiling = std::min<uint64_t>(ceiling, (freeBytes / 2 + (uint64_t)ctx->P * perPath) / perPath);
-    }
-    const uint64_t planes = std::max<uint64_t>(1, std::min<uint64_t>(ceiling / npt, (wantedPaths + npt - 1) / npt));
-    if (planes * npt > 0x7fffffffull) return RT_ERR_INVALID;
-    const uint32_t want = (uint32_t)(planes * npt);
-    if (ctx->pb.rays != nullptr && ctx->P >= want) return RT_OK;
+// (Re)allocates every per-path buffer for `want` paths.  ctx->P is zero while the set is incomplete,
+// so a failed attempt can never leave a capacity that some buffer does not have.
+int allocPathBuffers(rt_ctx *ctx, uint64_t want64) {
+    if (want64 > 0x7fffffffull) return RT_ERR_INVALID;
+    const uint32_t want = (uint32_t)want64;
+    ctx->P = 0;
     int rc;
     if ((rc = devAlloc(ctx, &ctx->pb.rays, (size_t)want * 2)) != RT_OK) return rc;
     if ((rc = devAlloc(ctx, &ctx->pb.hits, (size_t)want * 2)) != RT_OK) return rc;
@@ -1360,6 +1355,26 @@ int ensurePathBuffers(rt_ctx *ctx, uint64_t wantedPaths) {
     }
     ctx->P = want;
     return RT_OK;
+}
+
+// Makes room for min(wantedPaths, ceiling) paths, whole sample planes, at least one.  Grows only.
+int ensurePathBuffers(rt_ctx *ctx, uint64_t wantedPaths) {
+    const uint32_t npt = std::max(ctx->fp.npt, 1u);
+    uint64_t ceiling = ctx->maxPaths;
+    size_t freeBytes = 0, totalBytes = 0;
+    if (hipMemGetInfo(&freeBytes, &totalBytes) == hipSuccess) {
+        // Path state may take up to half of what is free now (plus what it already holds).
+        const uint64_t perPath = 2 * sizeof(RayRec) + 2 * sizeof(HitRec) + 5 * sizeof(float4) + 3 * sizeof(uint32_t) + 4;
+        ceiling = std::min<uint64_t>(ceiling, (freeBytes / 2 + (uint64_t)ctx->P * perPath) / perPath);
+    }
+    uint64_t planes = std::max<uint64_t>(1, std::min<uint64_t>(ceiling / npt, (wantedPaths + npt - 1) / npt));
+    if (ctx->pb.rays != nullptr && ctx->P >= planes * npt) return RT_OK;
+    // If the device cannot give that much after all, retry with half the planes.
+    for (;; planes = (planes + 1) / 2) {
+        const int rc = allocPathBuffers(ctx, planes * npt);
+        if (rc == RT_OK || rc != RT_ERR_HIP || planes == 1) return rc;
+        (void)hipGetLastError();
+    }
 }
 
 void launchTrace(rt_ctx *ctx, int extParity, int stage) {
