@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--bounces", type=int, default=4)
     ap.add_argument("--nu", type=int, default=2048)
     ap.add_argument("--nv", type=int, default=213)
+    ap.add_argument("--tex-size", type=int, default=0, help="texture edge of the textured scenes (0 = scene default)")
     ap.add_argument("--scene", default="cornell_knot")
     ap.add_argument("--spectral", action="store_true")
     ap.add_argument("--shard", choices=["sample", "tile"], default="sample",
@@ -67,7 +68,7 @@ def main():
 
     rtype = capi.RT_TYPE_SPECTRAL if args.spectral else capi.RT_TYPE_RGB
     t_build = time.time()
-    scene = capi.Scene(args.scene, nu=args.nu, nv=args.nv)
+    scene = capi.Scene(args.scene, nu=args.nu, nv=args.nv, tex_size=args.tex_size)
     t_build = time.time() - t_build
     cam = capi.make_camera(width=args.width, height=args.height, bounces=args.bounces, ray_per_pixel=1)
 

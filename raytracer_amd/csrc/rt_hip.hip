@@ -45,6 +45,9 @@ namespace {
 #ifndef RT_W20
 #define RT_W20 7
 #endif
+#ifndef RT_WALPHA
+#define RT_WALPHA 6   // alpha-cut variants: 80 VGPRs; at 7 waves/SIMD (72) they spill inside the main loop
+#endif
 constexpr int kStackDepth = 32;      // int stack[32], src/RayScene.cpp:682
 constexpr int kBlock = 256;
 constexpr int kMaxBounces = 62;      // stages kept on the device
@@ -200,8 +203,9 @@ __device__ __forceinline__ float slabDistance(V3 bmin, V3 bmax, V3 ro, V3 inv, f
 }
 
 // Alpha-cut rejection inside hitTriangle (src/RayScene.cpp:547-577).  Only
-// triangles flagged kTriAlphaTest at commit time come here.
-__device__ __noinline__ bool alphaCutRejects(const SceneView &sc, const PackedTri &pt, V3 ro, V3 rd, float t) {
+// triangles flagged kTriAlphaTest at commit time come here.  The traversal kernel
+// runs it in a phase of its own, where no node or triangle temporaries are live.
+__device__ __forceinline__ bool alphaCutRejects(const SceneView &sc, const PackedTri &pt, V3 ro, V3 rd, float t) {
     const ModelDesc &md = sc.modelDesc[pt.model & kTriModelMask];
     const float *idw = sc.models + md.identBase + pt.ident * kIdentWords;
     int32_t idx[3] = {f2i(idw[0]), f2i(idw[1]), f2i(idw[2])};
@@ -223,6 +227,12 @@ struct LaneRay {
     float bestU, bestV, mU, mV;
     uint32_t bestId, mBest, slot;
     int32_t ref, model, sp;
+    // Alpha-cut variant only: a candidate hit on an alpha-tested triangle waits here for the
+    // texture lookup (pendTri != kMiss), and `resume` is where the leaf loop continues afterwards.
+    // (Recomputing t,u,v in the lookup phase and folding `resume` into the leaf reference saves
+    // four registers here but makes the compiler spill inside the main loop: measured slower.)
+    float pendT, pendU, pendV;
+    uint32_t pendTri, resume;
 };
 
 __device__ __forceinline__ bool enterModel(const SceneView &sc, LaneRay &r, int m) {
@@ -237,6 +247,8 @@ __device__ __forceinline__ bool enterModel(const SceneView &sc, LaneRay &r, int 
         r.mBest = kMiss;
         r.mU = 0.0f;
         r.mV = 0.0f;
+        r.pendTri = kMiss;
+        r.resume = 0u;
         return true;
     }
     return false;
@@ -329,7 +341,7 @@ __device__ __forceinline__ void intersectPrimitives(const SceneView &sc, LaneRay
 // incoherent rays run best around 32).  The traversal stack of each lane lives
 // in LDS ([entry][lane], conflict free).
 template <bool COUNT, int STACK, bool ALPHA, bool PRIMS>
-__global__ __launch_bounds__(kBlock, (STACK <= 20 ? (PRIMS || ALPHA ? 7 : RT_W20) : STACK <= 24 ? 6 : 5)) void k_trace(SceneView sc, PathBuffers pb, int extParity, int stage, int refillLanes, int innerShare) {
+__global__ __launch_bounds__(kBlock, (STACK <= 20 ? (ALPHA ? RT_WALPHA : PRIMS ? 7 : RT_W20) : STACK <= 24 ? (ALPHA ? (RT_WALPHA < 6 ? RT_WALPHA : 6) : 6) : 5)) void k_trace(SceneView sc, PathBuffers pb, int extParity, int stage, int refillLanes, int innerShare) {
     __shared__ int32_t stackLds[kBlock / 64][STACK][64];
     const uint32_t lane = laneId();
     int32_t(*stack)[64] = stackLds[threadIdx.x >> 6];
@@ -419,8 +431,30 @@ __global__ __launch_bounds__(kBlock, (STACK <= 20 ? (PRIMS || ALPHA ? 7 : RT_W20
         // leaves the other lanes are parked on.  Lanes of the other kind wait, so each
         // phase runs with most lanes enabled instead of both code paths every iteration.
         const bool onInner = active && r.ref >= 0;
-        const int nActive = 64 - __popcll(__ballot(!active));
+        int nActive = 64 - __popcll(__ballot(!active));
         const int nInner = __popcll(__ballot(onInner));
+        if (ALPHA) {
+            // Third phase: candidate hits on alpha-tested triangles wait until eight lanes have one
+            // (or nothing else is left to do) and are then resolved together; the texture lookup
+            // needs many registers, and here none of the node/triangle temporaries are live.
+            const bool pending = active && r.pendTri != kMiss;
+            const int nPending = __popcll(__ballot(pending));
+            if (nPending > 0 && (nPending >= 8 || nPending == nActive)) {
+                if (pending) {
+                    if (!alphaCutRejects(sc, sc.tris[r.pendTri], r.ro, r.rd, r.pendT)) {
+                        r.tModel = r.pendT;
+                        r.maxT = r.pendT;
+                        r.mBest = r.pendTri;
+                        r.mU = r.pendU;
+                        r.mV = r.pendV;
+                    }
+                    r.resume = r.pendTri - ((~(uint32_t)r.ref) >> 2) + 1u;
+                    r.pendTri = kMiss;
+                }
+                continue;
+            }
+            nActive -= nPending;
+        }
         const bool innerPhase = nInner * 64 >= nActive * innerShare;
         bool pop = false, occluded = false;
         if (innerPhase) {
@@ -447,10 +481,11 @@ __global__ __launch_bounds__(kBlock, (STACK <= 20 ? (PRIMS || ALPHA ? 7 : RT_W20
                     pop = false;
                 }
             }
-        } else if (active && r.ref < 0) {
+        } else if (active && r.ref < 0 && !(ALPHA && r.pendTri != kMiss)) {
             const uint32_t code = ~(uint32_t)r.ref;
             const uint32_t first = code >> 2, ntri = code & 3u;
-            for (uint32_t k = 0; k < ntri; ++k) {
+            bool parked = false;
+            for (uint32_t k = ALPHA ? r.resume : 0u; k < ntri; ++k) {
                 if (COUNT) cntTris++;
                 const uint32_t ti = first + k;
                 const float4 *tp = reinterpret_cast<const float4 *>(&sc.tris[ti]);
@@ -468,7 +503,12 @@ __global__ __launch_bounds__(kBlock, (STACK <= 20 ? (PRIMS || ALPHA ? 7 : RT_W20
                 const float v = -dot(ab, dao) * invDet;
                 if (u < 0.0f || v < 0.0f || u + v > 1.0f) continue;
                 if (ALPHA && (__float_as_int(q1.w) & kTriAlphaTest)) {
-                    if (alphaCutRejects(sc, sc.tris[ti], r.ro, r.rd, t)) continue;
+                    r.pendT = t;
+                    r.pendU = u;
+                    r.pendV = v;
+                    r.pendTri = ti;
+                    parked = true;
+                    break;
                 }
                 r.tModel = t;
                 r.maxT = t;
@@ -476,8 +516,11 @@ __global__ __launch_bounds__(kBlock, (STACK <= 20 ? (PRIMS || ALPHA ? 7 : RT_W20
                 r.mU = u;
                 r.mV = v;
             }
-            pop = true;
-            occluded = r.tModel < r.tStop;
+            if (!parked) {
+                if (ALPHA) r.resume = 0u;
+                pop = true;
+                occluded = r.tModel < r.tStop;
+            }
         }
         if (pop) {
             if (r.sp > 0 && !occluded) {
@@ -1392,7 +1435,7 @@ void launchTrace(rt_ctx *ctx, int extParity, int stage) {
     const int depthClass = ctx->maxTreeDepth <= 20 ? 0 : ctx->maxTreeDepth <= 24 ? 1 : 2;
     const bool prims = ctx->objectCount > 0;
     const TraceFn fn = variants[ctx->countersOn ? 1 : 0][depthClass][ctx->hasAlphaTest ? 1 : 0][prims ? 1 : 0];
-    const int wavesPerSimd = depthClass == 0 ? ((prims || ctx->hasAlphaTest) ? 7 : RT_W20) : depthClass == 1 ? 6 : 5;
+    const int wavesPerSimd = depthClass == 0 ? (ctx->hasAlphaTest ? RT_WALPHA : prims ? 7 : RT_W20) : depthClass == 1 ? (ctx->hasAlphaTest ? std::min(RT_WALPHA, 6) : 6) : 5;
     const int grid = ctx->numCUs * wavesPerSimd;
     hipLaunchKernelGGL(fn, dim3(grid), dim3(kBlock), 0, ctx->stream, ctx->view, ctx->pb, extParity, stage, refill, ctx->innerShare);
     if (e1) hipEventRecord(e1, ctx->stream);

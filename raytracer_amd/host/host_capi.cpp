@@ -123,6 +123,26 @@ bool buildNamedScene(RayScene &scene, const std::string &name, const SceneParams
         scene.addObject(Sphere{glm::vec3{-0.5f, 0.3f, -0.3f}, 0.3f}, mirror);
         return true;
     }
+    if (name == "interior") {
+        // Interior-class stand-in: textured room (base colour, normal, metallic-roughness, emissive,
+        // occlusion, alpha-cut and transmission maps of texSize^2 texels), a second emissive panel and
+        // four displaced knots with different materials; 8*nu*nv + 16 triangles in six models.
+        scene.addModel(procedural::TexturedRoom(kBoxPos, 2.0f, p.texSize, p.seed));
+        scene.addModel(procedural::LightPanel(glm::vec3{-0.99f, 0.6f, -0.5f}, glm::vec3{0, 0.6f, 0}, glm::vec3{0, 0, 0.9f}, glm::vec3(1.0f, 0.8f, 0.6f), 5.0f));
+        Material metal;
+        metal.albedo = glm::vec3(0.95f, 0.8f, 0.5f);
+        metal.metallic = 1.0f;
+        metal.roughness = 0.2f;
+        Material wax;
+        wax.albedo = glm::vec3(0.8f, 0.45f, 0.35f);
+        wax.subsurface = 0.6f;
+        wax.roughness = 0.6f;
+        scene.addModel(procedural::KnotTube(p.nu, p.nv, glm::vec3{-0.45f, 0.45f, -0.25f}, 0.12f, p.seed + 11, knotDiffuse()));
+        scene.addModel(procedural::KnotTube(p.nu, p.nv, glm::vec3{0.45f, 0.5f, -0.1f}, 0.13f, p.seed + 12, metal));
+        scene.addModel(procedural::KnotTube(p.nu, p.nv, glm::vec3{-0.35f, 1.35f, 0.35f}, 0.12f, p.seed + 13, knotGlass()));
+        scene.addModel(procedural::KnotTube(p.nu, p.nv, glm::vec3{0.4f, 1.4f, 0.3f}, 0.11f, p.seed + 14, wax));
+        return true;
+    }
     if (name == "mixed") {
         // Non-light model first, then two light models: exercises the light-first
         // ordering of submit() and multi-model light selection.
