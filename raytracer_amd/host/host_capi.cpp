@@ -58,6 +58,11 @@ bool buildNamedScene(RayScene &scene, const std::string &name, const SceneParams
         RaySceneBuilder::ThreeColorDemo(scene);
         return true;
     }
+    if (name == "empty") return true;   // no objects, no models: every ray ends in the default sky
+    if (name == "unlit_knot") {         // a model but no light source anywhere: NEE finds nothing, the sky lights it
+        scene.addModel(procedural::KnotTube(p.nu, p.nv, glm::vec3{0.0f, 0.95f, 0.1f}, 0.25f, p.seed, knotDiffuse()));
+        return true;
+    }
     scene.setSkyColor(glm::vec3(0.0f));
     if (name.rfind("glb:", 0) == 0) {
         // "glb:a.glb;b.glb": one addModel(path) per file, in order, under a black sky

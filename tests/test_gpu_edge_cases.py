@@ -1,0 +1,111 @@
+"""GPU parity on the corners of the input space: empty and unlit scenes, zero bounces, one-pixel
+and ragged images, non-square sample counts, cameras inside geometry or looking away from it."""
+import numpy as np
+import pytest
+
+from raytracer_amd import capi
+from oracle_binding import OracleScene
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def backend():
+    b = capi.Backend(0)
+    yield b
+    b.close()
+
+
+def both(backend, name, kw, cam_kw, rtype, frames=2, first=1):
+    scene = capi.Scene(name, **kw)
+    cam = capi.make_camera(**cam_kw)
+    backend.upload_scene(scene)
+    backend.resize(cam_kw["width"], cam_kw["height"])
+    backend.set_frame(cam, scene.sky, rtype)
+    ids_gpu = backend.trace_primary(frame=first)
+    backend.render(first_frame=first, n_frames=frames, stride=1)
+    got, n = backend.readback()
+    orc = OracleScene(scene)
+    ids_cpu = orc.trace_primary(cam, frame=first)
+    want, st = orc.render(cam, rtype, first, frames, 1)
+    assert n == frames
+    for g, c in zip(ids_gpu, ids_cpu):
+        assert np.array_equal(g, c)
+    assert np.array_equal(got, want, equal_nan=True)
+    return scene, got, ids_gpu
+
+
+TYPES = [capi.RT_TYPE_RGB, capi.RT_TYPE_SPECTRAL]
+
+
+@pytest.mark.parametrize("rtype", TYPES)
+def test_empty_scene_is_sky_only(backend, rtype):
+    scene, img, ids = both(backend, "empty", {}, dict(width=33, height=17, bounces=4, ray_per_pixel=1), rtype)
+    assert scene.object_count == 0 and scene.models_count == 0
+    assert (ids[0] == -1).all() and np.isfinite(img).all()
+    if rtype == capi.RT_TYPE_RGB:
+        assert (img[..., :3] > 0).all()       # a single-wavelength Spectral sample may have negative RGB components
+
+
+@pytest.mark.parametrize("rtype", TYPES)
+def test_model_without_any_light_source(backend, rtype):
+    scene, img, ids = both(backend, "unlit_knot", dict(nu=64, nv=12), dict(width=40, height=30, bounces=3, ray_per_pixel=4), rtype)
+    assert scene.light_sources_count == 0
+    assert (ids[0] >= 0).any() and np.isfinite(img).all()
+
+
+@pytest.mark.parametrize("rtype", TYPES)
+@pytest.mark.parametrize("bounces", [0, 1, 16])
+def test_bounce_limits(backend, rtype, bounces):
+    both(backend, "mixed", dict(nu=32, nv=8), dict(width=32, height=24, bounces=bounces, ray_per_pixel=1), rtype)
+
+
+@pytest.mark.parametrize("w,h", [(1, 1), (1, 9), (9, 1), (7, 3), (8, 8), (65, 9)])
+def test_tiny_and_ragged_images(backend, w, h):
+    both(backend, "cornell_knot", dict(nu=32, nv=8), dict(width=w, height=h, bounces=2, ray_per_pixel=1), capi.RT_TYPE_RGB)
+
+
+@pytest.mark.parametrize("rtype", TYPES)
+@pytest.mark.parametrize("rpp", [2, 5, 16, 26])
+def test_sample_counts_that_are_not_squares(backend, rtype, rpp):
+    """ssq = int(sqrt(rayPerPixel)): 2 -> 1x1, 5 -> 2x2, 26 -> 5x5; the Spectral wavelength
+    stratum width still divides by rayPerPixel itself."""
+    both(backend, "cornell_quads", {}, dict(width=24, height=16, bounces=2, ray_per_pixel=rpp), rtype, frames=1)
+
+
+CAMERAS = {
+    "inside_the_knot_tube": dict(position=(0.5, 0.95, 0.1)),
+    "outside_looking_away": dict(position=(0.0, 1.0, -2.2), yaw=-90.0),
+    "looking_straight_up": dict(position=(0.0, 0.5, 0.0), pitch=89.0),
+    "grazing_the_floor": dict(position=(0.0, 1e-3, -0.9), pitch=0.0),
+    "wide_fov": dict(fov=150.0),
+    "narrow_fov": dict(fov=2.0),
+    "behind_the_back_wall": dict(position=(0.0, 1.0, 1.5)),
+}
+
+
+@pytest.mark.parametrize("case", sorted(CAMERAS))
+def test_camera_placements(backend, case):
+    cam = dict(width=48, height=32, bounces=3, ray_per_pixel=1)
+    cam.update(CAMERAS[case])
+    both(backend, "cornell_knot", dict(nu=96, nv=16), cam, capi.RT_TYPE_RGB)
+
+
+def test_frame_numbers_near_the_u32_limit(backend):
+    both(backend, "three_color", {}, dict(width=16, height=16, bounces=2, ray_per_pixel=1), capi.RT_TYPE_RGB, frames=2, first=0xFFFFFFF0)
+
+
+def test_bad_arguments_are_refused(backend):
+    scene = capi.Scene("three_color")
+    backend.upload_scene(scene)
+    backend.resize(16, 16)
+    for kw in (dict(ray_per_pixel=0), dict(bounces=-1), dict(bounces=10 ** 6), dict(width=17)):
+        args = dict(width=16, height=16, bounces=2, ray_per_pixel=1)
+        args.update(kw)
+        with pytest.raises(capi.RtError):
+            backend.set_frame(capi.make_camera(**args), scene.sky, capi.RT_TYPE_RGB)
+    with pytest.raises(capi.RtError):
+        backend.resize(0, 16)
+    backend.set_frame(capi.make_camera(width=16, height=16), scene.sky, capi.RT_TYPE_RGB)
+    with pytest.raises(capi.RtError):
+        backend.render(first_frame=1, n_frames=1, stride=0)
