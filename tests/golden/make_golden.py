@@ -4,8 +4,9 @@
 The reference renderer cannot be built or run offline and ships no fixtures, so
 these vectors are outputs of the checker itself (parity unpinned by the
 reference); they freeze the checker + host serialisation so that any later
-change to either, or to the HIP backend, is caught.  Re-run only on purpose:
-    python tests/golden/make_golden.py
+change to either, or to the HIP backend, is caught.  Writes only fixtures that are missing;
+name cases to regenerate them on purpose:
+    python tests/golden/make_golden.py [case ...]
 """
 import hashlib
 import os
@@ -21,14 +22,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 from raytracer_amd import capi  # noqa: E402
 from oracle_binding import OracleScene  # noqa: E402
 
-CASES = {
-    # name: (scene, kwargs, width, height, bounces, rayPerPixel, frames)
-    "cornell_quads": ("cornell_quads", {}, 48, 36, 4, 4, 2),
-    "cornell_knot": ("cornell_knot", dict(nu=96, nv=16), 48, 36, 4, 4, 2),
-    "textured_room": ("textured_room", dict(nu=48, nv=12, tex_size=32), 48, 36, 4, 4, 2),
-    "mixed": ("mixed", dict(nu=64, nv=12), 48, 36, 3, 1, 3),
-    "prism": ("prism", {}, 40, 40, 4, 4, 2),
-}
+from golden_cases import CASES, scene_name  # noqa: E402
 
 
 def stream_digest(scene):
@@ -39,8 +33,15 @@ def stream_digest(scene):
 
 
 def main():
+    only = set(sys.argv[1:])   # case names; default: the cases whose fixture is missing
+    glb = os.path.join(HERE, "room.glb")
+    if not os.path.exists(glb):
+        from glb_scenes import room_glb
+        room_glb(glb, nu=32, nv=10, tex=16)
     for case, (name, kw, W, H, bounces, rpp, frames) in CASES.items():
-        scene = capi.Scene(name, **kw)
+        if (only and case not in only) or (not only and os.path.exists(os.path.join(HERE, f"{case}.npz"))):
+            continue
+        scene = capi.Scene(scene_name(case), **kw)
         cam = capi.make_camera(width=W, height=H, bounces=bounces, ray_per_pixel=rpp)
         orc = OracleScene(scene)
         m, i, t, u, v, cnt = orc.trace_primary(cam, frame=1)

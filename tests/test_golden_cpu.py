@@ -6,14 +6,14 @@ import pytest
 
 from raytracer_amd import capi
 from oracle_binding import OracleScene
-from golden_cases import CASES, load
+from golden_cases import CASES, load, scene_name
 
 
 @pytest.mark.parametrize("case", sorted(CASES))
 def test_streams_and_checker_match_golden(case):
     name, kw, W, H, bounces, rpp, frames = CASES[case]
     g = load(case)
-    scene = capi.Scene(name, **kw)
+    scene = capi.Scene(scene_name(case), **kw)
     assert list(g["counts"]) == [scene.object_count, scene.models_count, scene.light_sources_count]
     assert list(g["stream_words"]) == [scene.streams[s].size for s in range(1, 6)]
     h = hashlib.sha256()

@@ -197,14 +197,14 @@ def test_ray_counts_match_checker(backend):
 
 
 # ---- committed golden vectors ------------------------------------------------------------
-from golden_cases import CASES as GOLDEN_CASES, load as load_golden  # noqa: E402
+from golden_cases import CASES as GOLDEN_CASES, load as load_golden, scene_name as golden_scene_name  # noqa: E402
 
 
 @pytest.mark.parametrize("case", sorted(GOLDEN_CASES))
 def test_gpu_matches_golden(backend, case):
     name, kw, W, H, bounces, rpp, frames = GOLDEN_CASES[case]
     g = load_golden(case)
-    scene, cam = _setup(backend, name, kw, W, H, bounces, rpp, capi.RT_TYPE_RGB)
+    scene, cam = _setup(backend, golden_scene_name(case), kw, W, H, bounces, rpp, capi.RT_TYPE_RGB)
     m, i, t, u, v = backend.trace_primary(frame=1)
     for key, got in (("model", m), ("ident", i), ("t", t), ("u", u), ("v", v)):
         assert np.array_equal(got, g[key]), key
