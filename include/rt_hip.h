@@ -166,8 +166,10 @@ int rt_set_counters(rt_ctx *ctx, int enabled);
  *   RT_OPT_MAX_PATHS         ceiling of paths in flight per batch (whole sample planes, at least
  *                            one; about 190 bytes of device memory per path).  Default 128 Mi,
  *                            further limited to half of the free device memory.  A render call
- *                            that needs fewer paths allocates only what it needs. */
-enum { RT_OPT_SHADOW_EARLY_OUT = 1, RT_OPT_REFILL_LANES = 2, RT_OPT_INNER_SHARE = 3, RT_OPT_MAX_PATHS = 4 };
+ *                            that needs fewer paths allocates only what it needs.
+ *   RT_OPT_TILE_MAJOR        order of the paths inside a batch: 1 (default) keeps all sample
+ *                            planes of an 8x8 pixel tile adjacent, 0 orders plane by plane */
+enum { RT_OPT_SHADOW_EARLY_OUT = 1, RT_OPT_REFILL_LANES = 2, RT_OPT_INNER_SHARE = 3, RT_OPT_MAX_PATHS = 4, RT_OPT_TILE_MAJOR = 5 };
 int rt_set_option(rt_ctx *ctx, int option, int value);
 
 const char *rt_strerror(int status);

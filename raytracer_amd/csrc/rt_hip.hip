@@ -81,7 +81,13 @@ struct Batch {
     uint32_t K;          // sample planes in this batch
     uint32_t firstFrame, frameStride;
     uint32_t P;          // capacity in paths; shadow-ray slots start at P
+    uint32_t planesInner;   // path order: 1 = tile-major (all K samples of a tile adjacent), 0 = plane-major
 };
+
+// Path index of sample plane k (0..K-1) of padded pixel q.  Tile-major order keeps the rays in
+// flight at any moment inside a small screen region, so they share the tree nodes they open.
+__device__ __forceinline__ uint32_t pathIndex(const FrameParams &fp, const Batch &bt, uint32_t k, uint32_t q);
+
 
 // Every ray queue is split into kSubQueues sub-queues, each with its length and
 // its consumer cursor on a 128-byte line of its own: a single queue word would
@@ -141,6 +147,10 @@ __device__ __forceinline__ bool pathPixel(const FrameParams &fp, uint32_t q, int
     return x < fp.W && y < fp.H && (tile % fp.tileStride) == fp.tileOffset;
 }
 
+__device__ __forceinline__ uint32_t pathIndex(const FrameParams &fp, const Batch &bt, uint32_t k, uint32_t q) {
+    return bt.planesInner ? ((((q >> 6) * bt.K + k) << 6) | (q & 63u)) : k * fp.npt + q;
+}
+
 // ---- k_generate -----------------------------------------------------------------------
 // Camera ray of fragment main() (src/RayTracer.cpp:559-578 / 1333-1366): jitter
 // in units of (1/W)*right and (1/H)*up, first draw horizontal.
@@ -152,7 +162,15 @@ __global__ __launch_bounds__(kBlock) void k_generate(FrameParams fp, Batch bt, P
         uint32_t p = base + laneId();
         bool valid = false;
         if (p < total) {
-            uint32_t k = p / fp.npt, q = p - k * fp.npt;
+            uint32_t k, q;
+            if (bt.planesInner) {
+                const uint32_t w = p >> 6;
+                k = w % bt.K;
+                q = ((w / bt.K) << 6) | (p & 63u);
+            } else {
+                k = p / fp.npt;
+                q = p - k * fp.npt;
+            }
             int x, y;
             valid = pathPixel(fp, q, x, y);
             if (valid) {
@@ -217,6 +235,12 @@ __device__ __forceinline__ bool alphaCutRejects(const SceneView &sc, const Packe
     V2 uv = cramerUV(tv.p[0], tv.p[1], tv.p[2], tv.uv[0], tv.uv[1], tv.uv[2], ro + t * rd);
     int at = texelOffset(sc, baseColor, uv);
     return sc.textures[at + 3] < alphaCut;
+}
+
+// Pins loaded values at this point of the program, so that the compiler cannot sink one of the
+// loads below a later branch (which turns one round trip to memory into two dependent ones).
+__device__ __forceinline__ void pinLoaded(const float4 &a, const float4 &b, const float4 &c) {
+    asm volatile("" : : "v"(a.x), "v"(a.w), "v"(b.x), "v"(b.w), "v"(c.x), "v"(c.w));
 }
 
 // Per-lane traversal state of the refilling variant.
@@ -490,6 +514,7 @@ __global__ __launch_bounds__(kBlock, (STACK <= 20 ? (ALPHA ? RT_WALPHA : PRIMS ?
                 const uint32_t ti = first + k;
                 const float4 *tp = reinterpret_cast<const float4 *>(&sc.tris[ti]);
                 const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
+                pinLoaded(q0, q1, q2);   // all three in one round trip, before the determinant test
                 const V3 A = v3(q0.x, q0.y, q0.z), ab = v3(q1.x, q1.y, q1.z), ac = v3(q2.x, q2.y, q2.z);
                 const V3 nrm = cross(ab, ac);
                 const float det = -dot(r.rd, nrm);
@@ -1049,7 +1074,7 @@ __global__ __launch_bounds__(kBlock) void k_resolve(FrameParams fp, Batch bt, Pa
                 float4 pc = partial[px];
                 c = v3(pc.x, pc.y, pc.z);
             }
-            const uint32_t path = k * fp.npt + q;
+            const uint32_t path = pathIndex(fp, bt, k, q);
             const float4 sB = pb.stB[path];
             if (SPECTRAL) {
                 const float lambda = pb.stA[path].z;
@@ -1140,6 +1165,7 @@ struct rt_ctx {
     bool hasAlphaTest = false;
     bool shadowEarlyOut = true;
     uint32_t tileOffset = 0, tileStride = 1;
+    bool planesInner = true;   // tile-major path order inside a batch
     int refillLanes = 32;   // idle lanes that trigger a refill for stages > 0
     int innerShare = 48;    // inner phase runs while >= innerShare/64 of the active lanes sit on inner nodes
 
@@ -1607,6 +1633,7 @@ int rt_create(rt_ctx **out, int device) {
         long v = std::atol(env);
         if (v > 0) ctx->maxPaths = (uint32_t)std::min<long>(v, 1l << 30);
     }
+    if (const char *env = std::getenv("RT_TILE_MAJOR")) ctx->planesInner = std::atoi(env) != 0;
     if (const char *env = std::getenv("RT_INNER_SHARE")) {
         int v = std::atoi(env);
         if (v >= 1 && v <= 64) ctx->innerShare = v;
@@ -1787,6 +1814,7 @@ int rt_render(rt_ctx *ctx, uint32_t first_frame, uint32_t n_frames, uint32_t fra
         bt.firstFrame = first_frame;
         bt.frameStride = frame_stride;
         bt.P = ctx->P;
+        bt.planesInner = ctx->planesInner ? 1u : 0u;
         if ((rc = runBatch(ctx, bt)) != RT_OK) return rc;
     }
     if (e1) hipEventRecord(e1, ctx->stream);
@@ -1902,6 +1930,7 @@ int rt_trace_primary(rt_ctx *ctx, uint32_t frame, int32_t *model, int32_t *ident
     bt.firstFrame = frame;
     bt.frameStride = 1;
     bt.P = ctx->P;
+    bt.planesInner = 0u;   // one plane: both orders coincide
     RT_HIP(hipMemsetAsync(ctx->pb.stages, 0, sizeof(Stage) * 2, ctx->stream));
     const int gGen = gridFor(ctx, fp.npt, 16);
     if (ctx->type == RT_TYPE_SPECTRAL) hipLaunchKernelGGL(k_generate<true>, dim3(gGen), dim3(kBlock), 0, ctx->stream, fp, bt, ctx->pb);
@@ -1990,6 +2019,9 @@ int rt_set_option(rt_ctx *ctx, int option, int value) {
         case RT_OPT_INNER_SHARE:
             if (value < 1 || value > 64) return RT_ERR_INVALID;
             ctx->innerShare = value;
+            return RT_OK;
+        case RT_OPT_TILE_MAJOR:
+            ctx->planesInner = value != 0;
             return RT_OK;
         case RT_OPT_MAX_PATHS:
             if (value < 1) return RT_ERR_INVALID;
