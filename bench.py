@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--spectral", action="store_true")
     ap.add_argument("--shard", choices=["sample", "tile"], default="sample",
                     help="N>1: sample-split (frames dealt round-robin) or tile-split (8x8 tiles dealt round-robin)")
+    ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend; gloo + --one-device rehearses the N>1 path on a single GPU")
+    ap.add_argument("--one-device", action="store_true", help="rehearsal only: every rank uses GPU 0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
     return ap.parse_args()
@@ -58,13 +60,16 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.one_device else int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP backend has no CPU fallback")
     torch.cuda.set_device(local_rank)
     distributed = world > 1
     if distributed:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.dist_backend)
 
     rtype = capi.RT_TYPE_SPECTRAL if args.spectral else capi.RT_TYPE_RGB
     t_build = time.time()
@@ -171,7 +176,7 @@ def main():
                 "workload": f"{args.scene} ({'procedural dragon-class mesh, ' if 'knot' in args.scene else ''}{triangles} triangles in {scene.models_count} models), "
                             f"{args.width}x{args.height}, {args.spp} spp per {'image' if tile_split else 'GPU'} per step, primary+{args.bounces} bounces, "
                             f"{'Spectral' if args.spectral else 'RGB'} NEE+MIS",
-                "sharding": (("tile-split 8x8 tiles" if tile_split else "sample-split frames") + ", scene replicated, RCCL sum-reduce of the fp32 accumulation buffer") if distributed else "single GPU",
+                "sharding": (("tile-split 8x8 tiles" if tile_split else "sample-split frames") + f", scene replicated, {'RCCL' if args.dist_backend == 'nccl' else args.dist_backend} sum-reduce of the fp32 accumulation buffer") if distributed else "single GPU",
                 "rays_per_camera_sample": round(total_rays / max(total_samples, 1), 4),
             },
             "spp_per_s": round(spp_per_s, 3),
