@@ -16,9 +16,11 @@
 //   * materials from pbrMetallicRoughness + the KHR volume/emissive_strength/transmission/ior
 //     extensions (src/MeshData.cpp:199-323);
 //   * textures: 8-bit images become k/255.0f texels (src/MeshData.cpp:475-528).  Images are
-//     decoded to RGBA like tinygltf's default loader does; only PNG (8-bit, non-interlaced)
-//     is decoded here — other encodings leave the texture without data, with a message.
+//     decoded to RGBA like tinygltf's default loader does; PNG (8-bit, non-interlaced, here) and
+//     baseline JPEG (JpegDecode.cpp) are decoded — other encodings leave the texture without
+//     data, with a message.
 #include "MeshData.h"
+#include "ImageIO.h"
 
 #include "glm/gtc/matrix_transform.hpp"
 #include "glm/gtc/quaternion.hpp"
@@ -489,8 +491,15 @@ void convertTexture(const Glb &glb, const Json &texture, MeshData::Texture &out)
     if (offset + length > glb.bin.size()) return;
     int w = 0, h = 0;
     std::vector<unsigned char> rgba;
-    if (!decodePngRGBA(glb.bin.data() + offset, length, w, h, rgba)) {
-        std::cout << "\tImage encoding not supported (only 8-bit non-interlaced PNG is decoded); texture left empty" << std::endl;
+    const unsigned char *bytes = glb.bin.data() + offset;
+    if (length >= 2 && bytes[0] == 0xFF && bytes[1] == 0xD8) {
+        std::string why;
+        if (!imageio::DecodeJpegRGBA(bytes, length, w, h, rgba, why)) {
+            std::cout << "\tJPEG image not decoded (" << why << "); texture left empty" << std::endl;
+            return;
+        }
+    } else if (!decodePngRGBA(bytes, length, w, h, rgba)) {
+        std::cout << "\tImage encoding not supported (8-bit non-interlaced PNG and baseline JPEG are decoded); texture left empty" << std::endl;
         return;
     }
     out.width = w;

@@ -5,7 +5,9 @@
 #pragma once
 
 #include <cstdint>
+#include <cstddef>
 #include <string>
+#include <vector>
 
 namespace imageio {
 
@@ -16,5 +18,9 @@ bool WritePNG(const std::string &path, const uint8_t *rgba8, int width, int heig
 // rgba: width*height*4 floats, row 0 = bottom row (PFM's own order); writes the three colour
 // channels scaled by `scale` (1/frames turns a sum buffer into the mean) as little-endian PFM.
 bool WritePFM(const std::string &path, const float *rgba, int width, int height, float scale);
+
+// Baseline (Huffman, 8-bit, greyscale or YCbCr) JPEG -> RGBA8, rows top-down.  On failure
+// `why` says what is unsupported or broken.
+bool DecodeJpegRGBA(const unsigned char *data, size_t size, int &width, int &height, std::vector<unsigned char> &rgba, std::string &why);
 
 }  // namespace imageio

@@ -227,3 +227,60 @@ def test_two_files_make_two_models(tmp_path):
     assert mats.shape[0] == 1 + 6 + 1
     d1 = decode_model(sc, 1)
     assert (d1["ident"][:, 3] == 7).all()      # second file's material 0 -> scene material 7
+
+
+JPEG_CASES = {
+    "444_q92": dict(quality=92, subsampling=0),
+    "422_q85": dict(quality=85, subsampling=1),
+    "420_q90": dict(quality=90, subsampling=2),
+    "420_q50_restart": dict(quality=50, subsampling=2, restart_marker_blocks=3),
+    "grey_q80": dict(quality=80),
+    "444_optimised": dict(quality=95, subsampling=0, optimize=True),
+}
+
+
+@pytest.mark.parametrize("case", sorted(JPEG_CASES))
+def test_jpeg_textures_are_close_to_an_independent_decoder(tmp_path, case):
+    """Baseline JPEG: decoders may differ by a few code values (inverse DCT rounding, chroma
+    upsampling filter, colour conversion); stb_image, which the reference uses, is not
+    available to compare with, so the bar is closeness to libjpeg (through PIL)."""
+    from PIL import Image
+    import io
+    rng = np.random.default_rng(11)
+    w, h = 37, 29                      # not multiples of the 8- or 16-pixel MCU
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = np.stack([128 + 100 * np.sin(xx / 5.0), 128 + 100 * np.cos(yy / 4.0), (xx * 7 + yy * 3) % 256], -1)
+    img = np.clip(img + rng.normal(0, 6, img.shape), 0, 255).astype(np.uint8)
+    pil = Image.fromarray(img, "RGB")
+    if case.startswith("grey"):
+        pil = pil.convert("L")
+    buf = io.BytesIO()
+    pil.save(buf, format="JPEG", **JPEG_CASES[case])
+    expect = np.asarray(Image.open(io.BytesIO(buf.getvalue())).convert("RGBA"), np.int32)
+
+    b = GlbBuilder()
+    t = b.texture(buf.getvalue())
+    b.doc["images"][0]["mimeType"] = "image/jpeg"
+    m = b.material(pbrMetallicRoughness={"baseColorTexture": {"index": t}})
+    p, n, uv, i = quad([0, 0, 0], [1, 0, 0], [0, 1, 0])
+    b.node(mesh=b.mesh([b.primitive(p, i, m, normals=n, uvs=uv)]), root=True)
+    tex = load(b.write(tmp_path / "jpeg.glb")).streams[5]
+    assert list(i32(tex[:3])) == [w, h, 4]
+    got = np.round(tex[5:].reshape(h, w, 4) * 255).astype(np.int32)
+    diff = np.abs(got - expect)
+    assert diff[..., 3].max() == 0
+    assert diff.max() <= 4 and diff.mean() <= 0.6, (diff.max(), diff.mean())
+
+
+def test_progressive_jpeg_is_refused_with_an_empty_texture(tmp_path):
+    from PIL import Image
+    import io
+    buf = io.BytesIO()
+    Image.fromarray(np.full((16, 16, 3), 90, np.uint8), "RGB").save(buf, format="JPEG", progressive=True)
+    b = GlbBuilder()
+    t = b.texture(buf.getvalue())
+    m = b.material(pbrMetallicRoughness={"baseColorTexture": {"index": t}})
+    p, n, uv, i = quad([0, 0, 0], [1, 0, 0], [0, 1, 0])
+    b.node(mesh=b.mesh([b.primitive(p, i, m, normals=n, uvs=uv)]), root=True)
+    tex = load(b.write(tmp_path / "prog.glb")).streams[5]
+    assert tex.size == 5 and list(i32(tex[:3])) == [0, 0, 0]      # header only, no texels
