@@ -22,7 +22,9 @@ typedef struct rth_engine rth_engine;
  * "cornell_knot", "knot_glass", "prism", "textured_room", "interior", "mixed", "empty", "unlit_knot", and
  * "glb:<a.glb>[;<b.glb>...]" = one RayScene::addModel(path) per binary glTF file under a black sky
  * (NULL if a file cannot be loaded).
- * iparams: [0]=knot nu, [1]=knot nv, [2]=texture size, [3]=seed (0 = defaults). */
+ * iparams: [0]=knot nu, [1]=knot nv, [2]=texture size, [3]=seed (0 = defaults),
+ * [4]=tree builder: 0 = process default (reference median split unless RT_BVH_MODE=sah),
+ * 1 = binned SAH (opt-in, not the reference's tree), 2 = reference median split. */
 rth_scene *rth_scene_build(const char *name, const int32_t *iparams, int n_iparams);
 void rth_scene_free(rth_scene *scene);
 

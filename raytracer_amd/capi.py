@@ -146,8 +146,8 @@ def write_pfm(path, rgba, scale=1.0):
 
 
 def _iparams(params):
-    arr = (C.c_int32 * 4)(*([int(p) for p in params] + [0] * (4 - len(params))))
-    return arr
+    vals = [int(p) for p in params]
+    return (C.c_int32 * len(vals))(*vals)
 
 
 def make_camera(position=(0.0, 1.0, -2.2), yaw=90.0, pitch=0.0, fov=50.0, width=64, height=64, bounces=4, ray_per_pixel=1):
@@ -163,9 +163,12 @@ def make_camera(position=(0.0, 1.0, -2.2), yaw=90.0, pitch=0.0, fov=50.0, width=
 class Scene:
     """A named scene built by the C++ host layer; exposes the five serialised streams."""
 
-    def __init__(self, name, nu=0, nv=0, tex_size=0, seed=0):
+    def __init__(self, name, nu=0, nv=0, tex_size=0, seed=0, bvh=None):
+        """bvh: None = process default (the reference's median split), "sah" = opt-in SAH trees, "reference"."""
         self.name = name
-        self._h = host.rth_scene_build(name.encode(), _iparams([nu, nv, tex_size, seed]), 4)
+        self._h = None
+        mode = {None: 0, "sah": 1, "reference": 2}[bvh]
+        self._h = host.rth_scene_build(name.encode(), _iparams([nu, nv, tex_size, seed, mode]), 5)
         if not self._h:
             raise RtError(f"unknown scene {name!r}")
         oc, mc, lc = C.c_int32(), C.c_int32(), C.c_int32()

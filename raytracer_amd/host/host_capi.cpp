@@ -16,6 +16,14 @@ namespace {
 struct SceneParams {
     int nu = 96, nv = 24, texSize = 64;
     u32 seed = 0xC0FFEEu;
+    BVHTree::Mode bvh = BVHTree::defaultMode();
+};
+
+// Models built while one of these is alive use the requested tree builder.
+struct BvhModeScope {
+    BVHTree::Mode saved = BVHTree::defaultMode();
+    explicit BvhModeScope(BVHTree::Mode m) { BVHTree::setDefaultMode(m); }
+    ~BvhModeScope() { BVHTree::setDefaultMode(saved); }
 };
 
 SceneParams parseParams(const int32_t *ip, int n) {
@@ -25,6 +33,8 @@ SceneParams parseParams(const int32_t *ip, int n) {
         if (n > 1 && ip[1] > 0) p.nv = ip[1];
         if (n > 2 && ip[2] > 0) p.texSize = ip[2];
         if (n > 3 && ip[3] != 0) p.seed = static_cast<u32>(ip[3]);
+        if (n > 4 && ip[4] == 1) p.bvh = BVHTree::Mode::SAH;
+        if (n > 4 && ip[4] == 2) p.bvh = BVHTree::Mode::Reference;
     }
     return p;
 }
@@ -187,7 +197,9 @@ rth_scene *rth_scene_build(const char *name, const int32_t *iparams, int n) {
     if (name == nullptr) return nullptr;
     auto holder = std::make_unique<rth_scene>();
     holder->scene.initialize(nullptr);
-    if (!buildNamedScene(holder->scene, name, parseParams(iparams, n))) return nullptr;
+    const SceneParams params = parseParams(iparams, n);
+    BvhModeScope scope(params.bvh);
+    if (!buildNamedScene(holder->scene, name, params)) return nullptr;
     holder->scene.submit();
     return holder.release();
 }
@@ -270,7 +282,9 @@ rth_engine *rth_engine_create(const char *scene_name, const int32_t *iparams, in
     auto holder = std::make_unique<rth_engine>();
     const RayCamera cam = makeCamera(position, yaw, pitch, fov, w, h, bounces, rpp);
     if (!holder->engine.initialize(cam, type == RT_TYPE_SPECTRAL ? RayTracer::Type::Spectral : RayTracer::Type::RGB, device)) return nullptr;
-    if (!buildNamedScene(holder->engine.getScene(), scene_name, parseParams(iparams, n))) return nullptr;
+    const SceneParams params = parseParams(iparams, n);
+    BvhModeScope scope(params.bvh);
+    if (!buildNamedScene(holder->engine.getScene(), scene_name, params)) return nullptr;
     holder->engine.getScene().submit();
     return holder.release();
 }

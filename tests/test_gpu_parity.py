@@ -368,3 +368,21 @@ def test_rccl_merge_entry_point_single_rank(backend):
     total, n2 = backend.readback()
     want, _ = OracleScene(scene).render(cam, 0, 1, 3, 1)
     assert n2 == 3 and np.array_equal(total, want)
+
+
+@pytest.mark.parametrize("rtype", [capi.RT_TYPE_RGB, capi.RT_TYPE_SPECTRAL])
+def test_sah_tree_mode_matches_checker(backend, rtype):
+    """The opt-in SAH trees go through the same streams and kernels: bit-exact against the checker on the same tree."""
+    W, H, frames = 64, 48, 2
+    scene = capi.Scene("mixed", nu=96, nv=16, bvh="sah")
+    cam = capi.make_camera(width=W, height=H, bounces=4, ray_per_pixel=4)
+    backend.upload_scene(scene)
+    backend.resize(W, H)
+    backend.set_frame(cam, scene.sky, rtype)
+    gm, gi, gt, gu, gv = backend.trace_primary(frame=1)
+    om, oi, ot, ou, ov, _ = OracleScene(scene).trace_primary(cam, frame=1)
+    assert np.array_equal(gm, om) and np.array_equal(gi, oi) and np.array_equal(gt, ot)
+    backend.render(first_frame=1, n_frames=frames, stride=1)
+    got, _ = backend.readback()
+    want, _ = OracleScene(scene).render(cam, rtype, 1, frames, 1)
+    assert np.array_equal(got, want, equal_nan=True)

@@ -85,9 +85,10 @@ def decode_model(sc, m):
     return dict(idents=idents, lights=lights, nodes=nodes, loc=loc, light=light, node=node_w, ident=ident, ident_f=ident_f, vert_at=at)
 
 
+@pytest.mark.parametrize("bvh", ["reference", "sah"])
 @pytest.mark.parametrize("name,kw", [("cornell_knot", dict(nu=64, nv=12)), ("mixed", dict(nu=48, nv=8)), ("textured_room", dict(nu=32, nv=8, tex_size=16))])
-def test_model_blob_and_bvh_invariants(name, kw):
-    sc = capi.Scene(name, **kw)
+def test_model_blob_and_bvh_invariants(name, kw, bvh):
+    sc = capi.Scene(name, bvh=bvh, **kw)
     words = sc.streams[4]
     seen_non_light = False
     expected_loc = 0
@@ -126,6 +127,8 @@ def test_model_blob_and_bvh_invariants(name, kw):
         assert covered.all()
         assert max(depth.values()) <= 32
         assert d["nodes"] == 2 * int(leaf.sum()) - 1
+        if bvh == "reference":
+            assert int(leaf.sum()) == 1 << int(np.ceil(np.log2(max(d["idents"], 2) / 2)))   # halving until <= 2 per leaf
         # light identifiers index the FIRST vertices of the model (src/MeshData.cpp:444-454)
         if d["lights"]:
             assert d["light"][:, :3].max() < 4 * d["lights"]
@@ -175,3 +178,24 @@ def test_full_size_bench_scene_shape():
     assert st["triangles"] == 872448 and st["vertices"] == 436224
     assert st["nodes"] == 2 * st["leaves"] - 1 == 1048575
     assert st["max_height"] == 20 and st["max_leaf_tris"] == 2 and st["valid"] == 1
+
+
+def test_sah_trees_render_the_same_image_with_fewer_visits():
+    """The opt-in SAH build changes only which nodes are opened: same closest hits (ties aside),
+    hence the same paths and the same image from the same seeds."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_binding import OracleScene
+    cam = capi.make_camera(width=64, height=48, bounces=3, ray_per_pixel=1)
+    out = {}
+    for mode in ("reference", "sah"):
+        sc = capi.Scene("mixed", nu=96, nv=16, bvh=mode)
+        orc = OracleScene(sc)
+        img, st = orc.render(cam, 0, 1, 2, 1)
+        _, _, t, u, v, _ = orc.trace_primary(cam, frame=1)
+        out[mode] = (img, st, t)
+    assert np.array_equal(out["reference"][2], out["sah"][2])
+    differing = int(np.any(out["reference"][0] != out["sah"][0], axis=-1).sum())
+    assert differing <= 2                                   # exact-tie pixels only, if any
+    assert out["sah"][1]["node_visits"] < 0.85 * out["reference"][1]["node_visits"]
+    assert out["sah"][1]["rays"] in range(out["reference"][1]["rays"] - 8, out["reference"][1]["rays"] + 9)
