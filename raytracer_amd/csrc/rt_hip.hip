@@ -212,12 +212,12 @@ __global__ __launch_bounds__(kBlock) void k_generate(FrameParams fp, Batch bt, P
 __device__ __forceinline__ float slabDistance(V3 bmin, V3 bmax, V3 ro, V3 inv, float t) {
     V3 tMin = (bmin - ro) * inv;
     V3 tMax = (bmax - ro) * inv;
-    V3 t1 = vmin(tMin, tMax);
-    V3 t2 = vmax(tMin, tMax);
-    float nearD = fmax_(fmax_(t1.x, t1.y), t1.z);
-    if (nearD > t) return 1e20f;
-    float farD = fmin_(fmin_(t2.x, t2.y), t2.z);
-    return (farD >= nearD && farD > 0.0f) ? nearD : 1e20f;
+    V3 t1 = v3(fminI_(tMin.x, tMax.x), fminI_(tMin.y, tMax.y), fminI_(tMin.z, tMax.z));
+    V3 t2 = v3(fmaxI_(tMin.x, tMax.x), fmaxI_(tMin.y, tMax.y), fmaxI_(tMin.z, tMax.z));
+    float nearD = fmax3_(t1.x, t1.y, t1.z);
+    float farD = fmin3_(t2.x, t2.y, t2.z);
+    // The reference returns early when nearD > t; as a select it is the same value without a branch.
+    return (!(nearD > t) && farD >= nearD && farD > 0.0f) ? nearD : 1e20f;
 }
 
 // Alpha-cut rejection inside hitTriangle (src/RayScene.cpp:547-577).  Only
