@@ -412,7 +412,10 @@ __global__ __launch_bounds__(kBlock, (STACK <= 20 ? (ALPHA ? RT_WALPHA : PRIMS ?
         const unsigned long long idleMask = __ballot(!active);
         const int nIdle = __popcll(idleMask);
         if (!drained && nIdle >= refillLanes) {
-            SubQueue *sq = (source < kSubQueues) ? &st->ext[source] : &st->shadow[source - kSubQueues];
+            // `source` is the same in every lane; saying so keeps the queue header in scalar registers
+            // and turns the load of its length into a scalar load.
+            const int src = __builtin_amdgcn_readfirstlane(source);
+            SubQueue *sq = (src < kSubQueues) ? &st->ext[src] : &st->shadow[src - kSubQueues];
             const uint32_t n = sq->count;
             const int leader = __ffsll((long long)idleMask) - 1;
             uint32_t base = n;
@@ -442,8 +445,8 @@ __global__ __launch_bounds__(kBlock, (STACK <= 20 ? (ALPHA ? RT_WALPHA : PRIMS ?
             } else {
                 const uint32_t mine = base + (uint32_t)__popcll(idleMask & ((1ull << lane) - 1ull));
                 if (!active && mine < n) {
-                    const uint32_t *q = (source < kSubQueues) ? qExt + (size_t)source * pb.subCap
-                                                                : pb.qShadow + (size_t)(source - kSubQueues) * pb.subCap;
+                    const uint32_t *q = (src < kSubQueues) ? qExt + (size_t)src * pb.subCap
+                                                             : pb.qShadow + (size_t)(src - kSubQueues) * pb.subCap;
                     r.slot = q[mine];
                     const float4 *rp = reinterpret_cast<const float4 *>(&pb.rays[r.slot]);
                     const float4 r0 = rp[0], r1 = rp[1];
