@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: Mrays/s of the path-traced hot path on MI355X.
 
-Workload (BASELINE.json configs[1]): dragon-class diffuse mesh (procedural
+Workload (the headline configuration): dragon-class diffuse mesh (procedural
 knot tube, 872,448 triangles) inside a Cornell box, 1920x1080, 64 samples per
 pixel (64 progressive frames x 1 sample), primary + 4 bounces, RGB integrator
 with NEE + MIS.  One *step* = those 64 spp over the whole image on every GPU.
@@ -191,6 +191,7 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": traffic,
+                "traffic_frac": (round(traffic / (st["trace_ms"] / launches * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if traffic else None),
                 "traffic_note": traffic_note,
                 "bytes_per_ray": round(b_ray, 1),
                 "nodes_per_ray": round(nodes_per_ray, 3),

@@ -240,7 +240,7 @@ def test_ray_engine_api_progressive_mean():
     assert rel_rmse(out, mean) < 1e-6
 
 
-# ---- BASELINE.json configs[1] at full size ---------------------------------------------------------
+# ---- the headline workload at full size ---------------------------------------------------------------
 @pytest.fixture(scope="module")
 def dragon_class():
     scene = capi.Scene("cornell_knot", nu=2048, nv=213)
