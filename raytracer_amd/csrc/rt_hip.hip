@@ -1255,6 +1255,28 @@ void drainEvents(rt_ctx *ctx) {
     fold(ctx->renderEvents, ctx->totalMs);
 }
 
+// Keeps the number of outstanding timing events bounded for callers that render many times
+// without ever synchronising: folds the pairs that have already completed and, if too many are
+// still pending, waits for the stream.
+void boundEvents(rt_ctx *ctx) {
+    constexpr size_t kReapAt = 1024, kSyncAt = 8192;
+    if (ctx->traceEvents.size() + ctx->renderEvents.size() < kReapAt) return;
+    auto reap = [ctx](std::vector<std::pair<hipEvent_t, hipEvent_t>> &v, double &acc) {
+        size_t done = 0;
+        while (done < v.size() && hipEventQuery(v[done].second) == hipSuccess) {
+            float ms = 0.0f;
+            if (hipEventElapsedTime(&ms, v[done].first, v[done].second) == hipSuccess) acc += ms;
+            ctx->eventPool.push_back(v[done].first);
+            ctx->eventPool.push_back(v[done].second);
+            ++done;
+        }
+        v.erase(v.begin(), v.begin() + (ptrdiff_t)done);
+    };
+    reap(ctx->traceEvents, ctx->traceMs);
+    reap(ctx->renderEvents, ctx->totalMs);
+    if (ctx->traceEvents.size() + ctx->renderEvents.size() >= kSyncAt && hipStreamSynchronize(ctx->stream) == hipSuccess) drainEvents(ctx);
+}
+
 int gridFor(const rt_ctx *ctx, uint64_t items, int blocksPerCU) {
     uint64_t want = (items + kBlock - 1) / kBlock;
     uint64_t cap = (uint64_t)ctx->numCUs * (uint64_t)blocksPerCU;
@@ -1832,6 +1854,7 @@ int rt_render(rt_ctx *ctx, uint32_t first_frame, uint32_t n_frames, uint32_t fra
     if (totalPlanes > 0xffffffffull) return RT_ERR_INVALID;
     int rc = ensurePathBuffers(ctx, totalPlanes * fp.npt);
     if (rc != RT_OK) return rc;
+    boundEvents(ctx);
 
     hipEvent_t e0 = takeEvent(ctx), e1 = takeEvent(ctx);
     if (e0) hipEventRecord(e0, ctx->stream);

@@ -109,3 +109,21 @@ def test_bad_arguments_are_refused(backend):
     backend.set_frame(capi.make_camera(width=16, height=16), scene.sky, capi.RT_TYPE_RGB)
     with pytest.raises(capi.RtError):
         backend.render(first_frame=1, n_frames=1, stride=0)
+
+
+def test_many_renders_without_a_sync_keep_the_timing_bookkeeping_bounded(backend):
+    """3000 one-frame render calls back to back (an interactive loop that never reads back):
+    the sum is still exact and the device time is still accounted for."""
+    scene = capi.Scene("three_color")
+    cam = capi.make_camera(width=16, height=16, bounces=1, ray_per_pixel=1)
+    backend.upload_scene(scene)
+    backend.resize(16, 16)
+    backend.set_frame(cam, scene.sky, capi.RT_TYPE_RGB)
+    backend.reset_stats()
+    for f in range(3000):
+        backend.render(first_frame=1 + f, n_frames=1, stride=1)
+    got, n = backend.readback()
+    st = backend.stats()
+    assert n == 3000 and st["trace_launches"] == 3000 * 3 and st["total_ms"] > 0
+    want, _ = OracleScene(scene).render(cam, capi.RT_TYPE_RGB, 1, 3000, 1)
+    assert np.array_equal(got, want)
