@@ -1731,6 +1731,7 @@ int rt_commit_scene(rt_ctx *ctx, int objectCount, int modelsCount, int lightSour
         return RT_OK;
     RT_HIP(hipSetDevice(ctx->device));
     RT_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->committed = false;   // a failed commit leaves the context without a scene, never with a stale one
     ctx->objectCount = objectCount;
     ctx->modelsCount = modelsCount;
     ctx->lightSourcesCount = lightSourcesCount;

@@ -127,3 +127,43 @@ def test_many_renders_without_a_sync_keep_the_timing_bookkeeping_bounded(backend
     assert n == 3000 and st["trace_launches"] == 3000 * 3 and st["total_ms"] > 0
     want, _ = OracleScene(scene).render(cam, capi.RT_TYPE_RGB, 1, 3000, 1)
     assert np.array_equal(got, want)
+
+
+def test_inconsistent_streams_are_refused_and_leave_no_scene(backend):
+    """Counts that do not match the uploaded streams, child references that point backwards and
+    vertex indices beyond the stream are caught at commit; rendering afterwards is a state error."""
+    import ctypes as C
+    hip = capi.hip
+    scene = capi.Scene("cornell_knot", nu=16, nv=6)
+    ctx = backend._ctx
+
+    def upload(streams):
+        for slot in range(1, 6):
+            a = np.ascontiguousarray(streams[slot], np.float32)
+            assert hip.rt_upload(ctx, slot, a.ctypes.data_as(C.c_void_p), a.nbytes) == 0
+
+    good = {s: scene.streams[s].copy() for s in range(1, 6)}
+    upload(good)
+    assert hip.rt_commit_scene(ctx, scene.object_count, scene.models_count + 1, scene.light_sources_count) == -5   # more models than info records
+    assert hip.rt_render(ctx, 1, 1, 1) == -2
+
+    info = good[3].view(np.int32).reshape(-1, 4)
+    bad = {s: v.copy() for s, v in good.items()}
+    node0 = int(info[1][3]) + int(info[1][1]) * 5                      # word offset of the knot's root node
+    bad[4].view(np.int32)[node0 + 6] = 0                               # left child = itself: a cycle
+    upload(bad)
+    assert hip.rt_commit_scene(ctx, scene.object_count, scene.models_count, scene.light_sources_count) == -5
+
+    bad = {s: v.copy() for s, v in good.items()}
+    ident0 = node0 + int(info[1][2]) * 9
+    bad[4].view(np.int32)[ident0] = 1 << 28                            # vertex index far beyond the stream
+    upload(bad)
+    assert hip.rt_commit_scene(ctx, scene.object_count, scene.models_count, scene.light_sources_count) == -5
+
+    bad = {s: v.copy() for s, v in good.items()}
+    bad[2] = bad[2][:23]                                               # identifiers name materials that are gone
+    upload(bad)
+    assert hip.rt_commit_scene(ctx, scene.object_count, scene.models_count, scene.light_sources_count) == -5
+
+    upload(good)
+    assert hip.rt_commit_scene(ctx, scene.object_count, scene.models_count, scene.light_sources_count) == 0
