@@ -20,7 +20,7 @@ HOST_SRCS := $(HOST)/AABB.cpp $(HOST)/BVHTree.cpp $(HOST)/MeshData.cpp $(HOST)/G
              $(HOST)/host_capi.cpp $(HOST)/gpu/HipStorage.cpp
 HOST_HDRS := $(wildcard $(HOST)/*.h $(HOST)/gpu/*.h $(HOST)/glm/*.hpp $(HOST)/glm/gtc/*.hpp) include/rt_hip.h include/rt_host.h
 
-all: $(LIBDIR)/librt_hip.so $(LIBDIR)/librt_host.so oracle/liboracle.so
+all: $(LIBDIR)/librt_hip.so $(LIBDIR)/librt_host.so oracle/liboracle.so examples/rt_render
 
 $(LIBDIR)/librt_hip.so: $(CSRC)/rt_hip.hip $(CSRC)/rt_device.h $(CSRC)/rt_bsdf.h $(CSRC)/rt_math.h include/rt_hip.h
 	@mkdir -p $(LIBDIR)
@@ -30,10 +30,14 @@ $(LIBDIR)/librt_host.so: $(HOST_SRCS) $(HOST_HDRS) $(LIBDIR)/librt_hip.so
 	@mkdir -p $(LIBDIR)
 	$(CXX) $(HOSTFLAGS) -shared $(HOST_SRCS) -o $@ -L$(LIBDIR) -lrt_hip -lz -Wl,-rpath,'$$ORIGIN'
 
+# Headless counterpart of the reference's main program, on the C++ host API.
+examples/rt_render: examples/render_main.cpp $(LIBDIR)/librt_host.so
+	$(CXX) $(HOSTFLAGS) examples/render_main.cpp -o $@ -L$(LIBDIR) -lrt_host -lrt_hip -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)'
+
 oracle/liboracle.so: oracle/oracle.cpp oracle/oracle_spectral.inc $(CSRC)/rt_math.h
 	$(MAKE) -C oracle liboracle.so
 
 clean:
-	rm -f $(LIBDIR)/*.so oracle/liboracle.so
+	rm -f $(LIBDIR)/*.so oracle/liboracle.so examples/rt_render
 
 .PHONY: all clean

@@ -386,3 +386,32 @@ def test_sah_tree_mode_matches_checker(backend, rtype):
     got, _ = backend.readback()
     want, _ = OracleScene(scene).render(cam, rtype, 1, frames, 1)
     assert np.array_equal(got, want, equal_nan=True)
+
+
+def test_cpp_example_program_renders_the_same_picture(tmp_path):
+    """examples/rt_render drives the C++ host API the way the reference's main() does; its PNG must
+    equal the display pass of the same scene rendered through the C ABI from here."""
+    import os
+    import subprocess
+    from PIL import Image
+    from glb_scenes import room_glb
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "rt_render")
+    assert os.path.exists(exe), "build it with `make`"
+    glb = room_glb(tmp_path / "room.glb", nu=24, nv=8)
+    out = tmp_path / "cpp.png"
+    run = subprocess.run([exe, "--rgb", "--frames", "3", "--size", "64x48", "--bounces", "4", "--out", str(out), glb],
+                         capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0, run.stderr
+    b = capi.Backend(0)
+    try:
+        scene = capi.Scene("glb:" + glb)
+        cam = capi.make_camera(width=64, height=48, bounces=4, ray_per_pixel=1)
+        b.upload_scene(scene)
+        b.resize(64, 48)
+        b.set_frame(cam, scene.sky, capi.RT_TYPE_RGB)
+        b.render(first_frame=1, n_frames=3, stride=1)
+        want = b.display_rgba8()[::-1]        # the PNG is stored top-down
+    finally:
+        b.close()
+    assert np.array_equal(np.asarray(Image.open(out)), want)
