@@ -19,7 +19,7 @@ typedef struct rth_engine rth_engine;
 
 /* Builds one of the named scenes into a host-only RayScene (streams kept on the
  * host) and submits it.  Names: "cornell_quads", "roughness_demo", "three_color",
- * "cornell_knot", "knot_glass", "prism", "textured_room", "interior", "mixed", "empty", "unlit_knot", and
+ * "cornell_knot", "knot_glass", "prism", "textured_room", "interior", "mixed", "empty", "unlit_knot", "fuzz" (random soup: nu triangles, nv materials), and
  * "glb:<a.glb>[;<b.glb>...]" = one RayScene::addModel(path) per binary glTF file under a black sky
  * (NULL if a file cannot be loaded).
  * iparams: [0]=knot nu, [1]=knot nv, [2]=texture size, [3]=seed (0 = defaults),

@@ -253,4 +253,88 @@ MeshData TexturedRoom(glm::vec3 pos, float L, int texSize, u32 seed) {
     return mesh;
 }
 
+MeshData RandomSoup(glm::vec3 pos, float L, int nTris, int nMaterials, int nLights, u32 seed) {
+    u32 state = seed * 2654435761u + 12345u;
+    auto u01 = [&state]() {
+        state = mix32(state + 0x9E3779B9u);
+        return static_cast<float>(state >> 8) * (1.0f / 16777216.0f);
+    };
+    auto pick = [&](std::initializer_list<float> corners, float lo, float hi) {
+        // One time in three a corner value, otherwise uniform in [lo, hi].
+        if (u01() < 0.34f) {
+            const size_t k = static_cast<size_t>(u01() * static_cast<float>(corners.size()));
+            return *(corners.begin() + (k < corners.size() ? k : corners.size() - 1));
+        }
+        return lo + (hi - lo) * u01();
+    };
+
+    MeshData lights, mesh;
+    const int nTextures = 4;
+    for (int t = 0; t < nTextures; ++t)
+        mesh.textures.push_back(CheckerTexture(4 + 4 * t, 8, t % 2 ? 3 : 4, seed + 17u * static_cast<u32>(t), t == 1 ? 33071 : 10497, t == 2 ? 33648 : 10497));
+    nMaterials = nMaterials < 2 ? 2 : nMaterials;
+    for (int m = 0; m < nMaterials; ++m) {
+        Material mat;
+        mat.albedo = glm::vec3(pick({0.0f, 1.0f}, 0.05f, 0.95f), pick({0.0f, 1.0f}, 0.05f, 0.95f), pick({0.0f, 1.0f}, 0.05f, 0.95f));
+        mat.subsurface = pick({0.0f, 1.0f}, 0.0f, 1.0f);
+        mat.roughness = pick({0.0f, 1.0f, 1e-4f}, 0.02f, 1.0f);
+        mat.metallic = pick({0.0f, 1.0f}, 0.0f, 1.0f);
+        mat.specular = pick({0.0f, 1.0f, 0.5f}, 0.0f, 1.0f);
+        mat.specularTint = pick({0.0f, 1.0f}, 0.0f, 1.0f);
+        mat.transmission = pick({0.0f, 0.0f, 1.0f}, 0.0f, 1.0f);
+        mat.ior = pick({1.0f, 1.5f, 2.4f}, 1.01f, 2.0f);
+        mat.normalScale = pick({-1.0f, 1.0f}, 0.1f, 2.0f);
+        mat.occlusionStrength = pick({0.0f, 1.0f}, 0.0f, 1.0f);
+        if (m == 0) {                      // material 0 is the light set's
+            mat.emissionColor = glm::vec3(1.0f, 0.9f, 0.8f);
+            mat.emissionStrength = 12.0f;
+        } else if (u01() < 0.15f) {        // stray emitters that are not in the light set
+            mat.emissionColor = glm::vec3(u01(), u01(), u01());
+            mat.emissionStrength = 3.0f * u01();
+        }
+        if (m > 0 && u01() < 0.5f) {
+            auto tex = [&]() { return u01() < 0.5f ? static_cast<i32>(u01() * nTextures) % nTextures : -1; };
+            mat.texture.baseColorTexture = tex();
+            mat.texture.metallicRoughnessTexture = tex();
+            mat.texture.normalTexture = tex();
+            mat.texture.emissiveTexture = tex();
+            mat.texture.occlusionTexture = tex();
+            mat.texture.transmissionTexture = tex();
+            if (mat.texture.baseColorTexture >= 0 && u01() < 0.5f) mat.alphaCut = 0.2f + 0.6f * u01();
+        }
+        mesh.materials.push_back(mat);
+    }
+
+    auto addTriangle = [&](MeshData &dst, i32 material) {
+        const glm::vec3 c = pos + glm::vec3(u01(), u01(), u01()) * L;
+        const float size = (u01() < 0.2f ? 0.6f : 0.15f) * L * (0.2f + u01());
+        glm::vec3 p[3];
+        for (auto &v : p) v = c + glm::vec3(u01() - 0.5f, u01() - 0.5f, u01() - 0.5f) * size;
+        const float kind = u01();
+        if (kind < 0.02f) p[2] = p[1];                                   // zero-area triangle
+        else if (kind < 0.04f) p[2] = p[0] + (p[1] - p[0]) * 2.0f;        // three collinear points
+        const i32 base = static_cast<i32>(dst.vertices.size());
+        glm::vec3 g = glm::cross(p[1] - p[0], p[2] - p[0]);
+        const float normalKind = u01();
+        for (int k = 0; k < 3; ++k) {
+            MeshData::Vertex v;
+            v.position = p[k];
+            if (normalKind < 0.3f) v.normal = glm::vec3(0.0f);                                         // geometric normal is used
+            else if (normalKind < 0.7f && glm::dot(g, g) > 0.0f) v.normal = glm::normalize(g);
+            else v.normal = glm::vec3(u01() - 0.5f, u01() - 0.5f, u01() - 0.5f);                      // skewed, not unit length
+            v.uv = glm::vec2(u01() * 3.0f - 1.0f, u01() * 3.0f - 1.0f);                                // beyond [0,1]: wrapping
+            dst.vertices.push_back(v);
+        }
+        MeshData::Identifier id;
+        id.index = glm::ivec3(base, base + 1, base + 2);
+        id.materialIndex = material;
+        dst.identifiers.push_back(id);
+    };
+    for (int t = 0; t < nLights; ++t) addTriangle(lights, 0);
+    for (int t = nLights; t < nTris; ++t) addTriangle(mesh, 1 + static_cast<i32>(u01() * static_cast<float>(nMaterials - 1)) % (nMaterials - 1));
+    mesh.adoptLights(lights);
+    mesh.deriveTextureFlags();
+    return mesh;
+}
+
 }  // namespace procedural

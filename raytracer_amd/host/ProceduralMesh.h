@@ -33,4 +33,11 @@ MeshData::Texture CheckerTexture(int width, int height, int channels, u32 seed, 
 // texture branch of the material resolver.
 MeshData TexturedRoom(glm::vec3 pos, float boxLen, int texSize, u32 seed);
 
+// Random triangle soup inside the box [pos, pos+boxLen]^3 for differential testing: `nTris`
+// triangles of mixed sizes (a few degenerate), vertex normals that are zero, unit or skewed,
+// `nMaterials` materials with every field drawn at random (including the corners: roughness 0,
+// ior 1, full transmission, alpha cut, emission) and small random textures on some of them.
+// The first `nLights` triangles are emissive and form the model's light set.
+MeshData RandomSoup(glm::vec3 pos, float boxLen, int nTris, int nMaterials, int nLights, u32 seed);
+
 }  // namespace procedural

@@ -158,6 +158,28 @@ bool buildNamedScene(RayScene &scene, const std::string &name, const SceneParams
         scene.addModel(procedural::KnotTube(p.nu, p.nv, glm::vec3{0.4f, 1.4f, 0.3f}, 0.11f, p.seed + 14, wax));
         return true;
     }
+    if (name == "fuzz") {
+        // Differential-testing scene: two random soups (nu triangles each, nv materials; the second
+        // without lights), random analytic primitives, sky colour from the seed.
+        u32 st = p.seed * 747796405u + 1u;
+        auto u01 = [&st]() { st = st * 1664525u + 1013904223u; return static_cast<float>(st >> 8) * (1.0f / 16777216.0f); };
+        scene.setSkyColor((p.seed & 1u) ? glm::vec3(u01(), u01(), u01()) : glm::vec3(0.0f));
+        scene.addModel(procedural::RandomSoup(kBoxPos, 2.0f, p.nu, p.nv, 3, p.seed));
+        scene.addModel(procedural::RandomSoup(kBoxPos + glm::vec3(0.3f, 0.2f, 0.4f), 1.4f, p.nu / 2 + 3, p.nv, 0, p.seed + 99u));
+        for (int k = 0; k < 5; ++k) {
+            Material m;
+            m.albedo = glm::vec3(u01(), u01(), u01());
+            m.roughness = u01();
+            m.metallic = u01() < 0.5f ? 0.0f : 1.0f;
+            m.transmission = u01() < 0.3f ? 1.0f : 0.0f;
+            if (k == 0) { m.emissionColor = glm::vec3(1.0f); m.emissionStrength = 5.0f; }
+            const glm::vec3 c = kBoxPos + glm::vec3(u01(), u01(), u01()) * 2.0f;
+            if (k % 3 == 0) scene.addObject(Sphere{c, 0.1f + 0.3f * u01()}, m);
+            else if (k % 3 == 1) scene.addObject(Quad{c, glm::vec3{0.5f * u01(), 0, 0.2f}, glm::vec3{0, 0.5f * u01(), 0.1f}}, m);
+            else scene.addObject(Triangle{c, c + glm::vec3{0.4f, 0.1f, 0}, c + glm::vec3{0, 0.5f, 0.3f}}, m);
+        }
+        return true;
+    }
     if (name == "mixed") {
         // Non-light model first, then two light models: exercises the light-first
         // ordering of submit() and multi-model light selection.

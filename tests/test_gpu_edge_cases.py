@@ -167,3 +167,12 @@ def test_inconsistent_streams_are_refused_and_leave_no_scene(backend):
 
     upload(good)
     assert hip.rt_commit_scene(ctx, scene.object_count, scene.models_count, scene.light_sources_count) == 0
+
+
+@pytest.mark.parametrize("rtype", TYPES)
+@pytest.mark.parametrize("seed", list(range(1, 13)))
+def test_random_soups_with_random_materials(backend, rtype, seed):
+    """Differential test: random triangles (some degenerate), skewed normals, every material field
+    at random including the corner values, random textures and analytic primitives."""
+    nu = 40 if seed % 4 == 0 else 400          # shallow and deeper trees
+    _, img, _ = both(backend, "fuzz", dict(nu=nu, nv=10, seed=seed), dict(width=56, height=40, bounces=6, ray_per_pixel=4), rtype)
