@@ -187,3 +187,70 @@ def test_oracle_mean_matches_sum_for_reference_progression():
     rgba, mean, _ = OracleScene(scene).render(cam, 0, 1, 5, 1, want_mean=True)
     assert np.allclose(mean[..., :3], rgba[..., :3] / 5.0, rtol=2e-6, atol=1e-7)
     assert np.all(rgba[..., 3] == 5.0)
+
+
+@pytest.mark.parametrize("name,kw", [("cornell_knot", dict(nu=64, nv=12)), ("unlit_knot", dict(nu=96, nv=10)), ("fuzz", dict(nu=300, nv=6, seed=5))])
+def test_tree_traversal_finds_what_brute_force_finds(name, kw):
+    """Independent check of the host tree build + the checker's traversal and triangle test: the
+    closest hit of every primary ray, by float64 Moller-Trumbore over ALL triangles decoded from
+    the serialised streams (no tree), must be the checker's hit.  Pixels whose best and second
+    best distances are within 1e-6 of each other are excluded (ties and silhouettes)."""
+    from test_host_layer import decode_model, i32
+    scene = capi.Scene(name, **kw)
+    W, H = 48, 36
+    cam = capi.make_camera(width=W, height=H, bounces=1, ray_per_pixel=1)
+    om, oi, ot, ou, ov, _ = OracleScene(scene).trace_primary(cam, frame=1)
+
+    tris, owner, alpha = [], [], []
+    info = i32(scene.streams[3]).reshape(-1, 4)
+    for m in range(scene.models_count):
+        d = decode_model(scene, m)
+        end = info[m + 1][3] if m + 1 < scene.models_count else scene.streams[4].size
+        verts = scene.streams[4][d["vert_at"]: end].reshape(-1, 8)[:, :3].astype(np.float64)
+        mats = scene.streams[2].reshape(-1, 23)
+        for k, ident in enumerate(d["ident"]):
+            tris.append(verts[ident[:3]])
+            owner.append((m, k))
+            mat = mats[ident[3]]
+            alpha.append(bool(d["ident_f"][k, 4] != 0) and i32(mat[:6])[1] != -1 and mat[20] > 0)
+    tris = np.array(tris)                       # (T, 3, 3)
+    alpha = np.array(alpha)                     # triangles that a texture lookup may make transparent
+    A, ab, ac = tris[:, 0], tris[:, 1] - tris[:, 0], tris[:, 2] - tris[:, 0]
+    nrm = np.cross(ab, ac)
+
+    checked = 0
+    for y in range(H):
+        for x in range(W):
+            out = (C.c_float * 6)()
+            lib.orc_camera_ray(C.byref(cam), x, y, 1, out)
+            ro, rd = np.array(out[:3], np.float64), np.array(out[3:], np.float64)
+            det = -(nrm @ rd)
+            ok = np.abs(det) > 1e-12
+            ao = ro - A
+            dao = np.cross(ao, rd)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                t = np.einsum("ij,ij->i", ao, nrm) / det
+                u = np.einsum("ij,ij->i", ac, dao) / det
+                v = -np.einsum("ij,ij->i", ab, dao) / det
+                hit = ok & (t > 0) & (u >= 0) & (v >= 0) & (u + v <= 1)
+            ts = np.where(hit & ~alpha, t, np.inf)
+            if (hit & alpha & (t <= ts.min() + 1e-6)).any():
+                continue                                   # an alpha-cut triangle in front: its fate depends on a texel
+            order = np.argsort(ts)
+            best, second = ts[order[0]], ts[order[1]]
+            margin_uv = min(u[order[0]], v[order[0]], 1 - u[order[0]] - v[order[0]]) if np.isfinite(best) else 1.0
+            if scene.object_count and om[y, x] == -2:
+                continue                                   # an analytic primitive is closer; covered by the closed-form tests
+            if not np.isfinite(best):
+                if scene.object_count == 0:
+                    assert om[y, x] == -1, (x, y)
+                continue
+            if second - best < 1e-6 or margin_uv < 1e-5:
+                continue
+            if scene.object_count and ot[y, x] < best - 1e-5:
+                continue                                   # a primitive in front (reported as model -2 above) or beside
+            checked += 1
+            assert (om[y, x], oi[y, x]) == owner[order[0]], (x, y, best)
+            assert abs(ot[y, x] - best) <= 1e-5 * best
+            assert abs(ou[y, x] - u[order[0]]) <= 2e-4 and abs(ov[y, x] - v[order[0]]) <= 2e-4
+    assert checked > 100                       # enough pixels really went through the comparison
