@@ -68,6 +68,19 @@ bool buildNamedScene(RayScene &scene, const std::string &name, const SceneParams
         RaySceneBuilder::ThreeColorDemo(scene);
         return true;
     }
+    if (name == "furnace") {
+        // White-furnace check: a uniformly white environment around one sphere whose material is
+        // chosen by nu (0 matte white, 1 rough white metal, 2 clear glass, 3 white subsurface).
+        scene.setSkyColor(glm::vec3(1.0f));
+        Material m;
+        m.albedo = glm::vec3(1.0f);
+        m.specular = 0.0f;
+        if (p.nu == 1) { m.metallic = 1.0f; m.roughness = 0.6f; }
+        if (p.nu == 2) { m.transmission = 1.0f; m.roughness = 0.0f; }
+        if (p.nu == 3) { m.subsurface = 1.0f; }
+        scene.addObject(Sphere{glm::vec3{0.0f, 1.0f, 0.0f}, 0.8f}, m);
+        return true;
+    }
     if (name == "empty") return true;   // no objects, no models: every ray ends in the default sky
     if (name == "unlit_knot") {         // a model but no light source anywhere: NEE finds nothing, the sky lights it
         scene.addModel(procedural::KnotTube(p.nu, p.nv, glm::vec3{0.0f, 0.95f, 0.1f}, 0.25f, p.seed, knotDiffuse()));

@@ -254,3 +254,19 @@ def test_tree_traversal_finds_what_brute_force_finds(name, kw):
             assert abs(ot[y, x] - best) <= 1e-5 * best
             assert abs(ou[y, x] - u[order[0]]) <= 2e-4 and abs(ov[y, x] - v[order[0]]) <= 2e-4
     assert checked > 100                       # enough pixels really went through the comparison
+
+
+def test_white_furnace():
+    """A white sphere in a uniformly white environment (sanity of pdfs and weights, not a pin):
+    clear glass returns the environment exactly in RGB, a matte white sphere within the few
+    per cent the Disney diffuse term adds at grazing angles, rough white metal loses a little."""
+    cam = capi.make_camera(width=48, height=36, bounces=12, ray_per_pixel=16)
+    means = {}
+    for kind in (0, 1, 2):
+        orc = OracleScene(capi.Scene("furnace", nu=kind))
+        on = orc.trace_primary(cam)[0] == -2
+        img, _ = orc.render(cam, 0, 1, 4, 1)
+        means[kind] = float((img[..., :3] / 4)[on].mean())
+    assert means[2] == pytest.approx(1.0, abs=1e-6)
+    assert 0.98 < means[0] < 1.12
+    assert 0.90 < means[1] < 1.02
