@@ -153,7 +153,7 @@ int rt_reset_stats(rt_ctx *ctx);
 /* Enables per-ray node/triangle visit counting (slower; off by default). */
 int rt_set_counters(rt_ctx *ctx, int enabled);
 
-/* Tuning switches (no reference counterpart).  None of them changes any output value.
+/* Switches (no reference counterpart).  Only RT_OPT_SPECTRAL_PDF_AS_WRITTEN changes output values.
  *   RT_OPT_SHADOW_EARLY_OUT  RGB shadow rays stop at the first hit nearer than
  *                            distToLight - 1e-4: such a hit already fails the reference's
  *                            visibility test (src/RayTracer.cpp:439), so finishing the
@@ -167,9 +167,16 @@ int rt_set_counters(rt_ctx *ctx, int enabled);
  *                            one; about 190 bytes of device memory per path).  Default 128 Mi,
  *                            further limited to half of the free device memory.  A render call
  *                            that needs fewer paths allocates only what it needs.
+ *   RT_OPT_SPECTRAL_PDF_AS_WRITTEN   The Spectral shader text does not link against the shared scene
+ *                            code (it calls a 2-argument light sampler, src/RayTracer.cpp:783,1150,
+ *                            while src/RayScene.cpp:900 defines three).  0 (default): the sampler's
+ *                            triangle count is used and the area pdf is 1/area/lightSources/
+ *                            lightTriangles as in the RGB integrator (src/RayTracer.cpp:363-365,
+ *                            427).  1: pdf = 1/area, literally as src/RayTracer.cpp:1082,1165 write it.
  *   RT_OPT_TILE_MAJOR        order of the paths inside a batch: 1 (default) keeps all sample
  *                            planes of an 8x8 pixel tile adjacent, 0 orders plane by plane */
-enum { RT_OPT_SHADOW_EARLY_OUT = 1, RT_OPT_REFILL_LANES = 2, RT_OPT_INNER_SHARE = 3, RT_OPT_MAX_PATHS = 4, RT_OPT_TILE_MAJOR = 5 };
+enum { RT_OPT_SHADOW_EARLY_OUT = 1, RT_OPT_REFILL_LANES = 2, RT_OPT_INNER_SHARE = 3, RT_OPT_MAX_PATHS = 4, RT_OPT_TILE_MAJOR = 5,
+       RT_OPT_SPECTRAL_PDF_AS_WRITTEN = 6 };
 int rt_set_option(rt_ctx *ctx, int option, int value);
 
 const char *rt_strerror(int status);

@@ -86,6 +86,9 @@ struct Ctx {
     V3 skyColor;
     uint32_t frameCount;
     Counters cnt;
+    // Spectral integrator only: leave the light-selection probability out of the area pdf, as the
+    // Spectral shader text has it (type bit 8 of orc_render); default is the RGB convention.
+    bool spectralPdfAsWritten = false;
 };
 
 // ---- GLSL structs (src/RayTracer.cpp:43-88, src/RayScene.cpp:215-257) -------------
@@ -1036,13 +1039,15 @@ int orc_trace_primary(const orc_scene *s, const Camera *cam, uint32_t frame, int
 // running mean (prev*(n-1)+c)/n with n = the frame number itself, which equals
 // the plain mean only for first_frame = 1, stride = 1.
 // stats = {rays, nodeVisits, triTests, shadedHits, cameraSamples}.
-int orc_render(const orc_scene *s, const Camera *cam, const float sky[3], int type, uint32_t first_frame, uint32_t n_frames, uint32_t stride,
+int orc_render(const orc_scene *s, const Camera *cam, const float sky[3], int typeAndFlags, uint32_t first_frame, uint32_t n_frames, uint32_t stride,
                int x0, int y0, int x1, int y1, float *rgba_sum, float *rgba_mean, uint64_t stats[5], int threads) {
     if (s == nullptr || cam == nullptr || sky == nullptr || rgba_sum == nullptr) return -1;
     const int W = (int)cam->resolution[0];
+    const int type = typeAndFlags & 0xff;
     std::vector<Counters> per((size_t)std::max(threads, 1));
     parallelRows(y0, y1, threads, [&](int y, int tid) {
         Ctx c{&s->sc, *cam, v3(sky[0], sky[1], sky[2]), 0u, Counters()};
+        c.spectralPdfAsWritten = (typeAndFlags & 0x100) != 0;
         for (int x = x0; x < x1; ++x) {
             size_t at = ((size_t)y * W + x) * 4;
             for (uint32_t k = 0; k < n_frames; ++k) {

@@ -71,6 +71,7 @@ struct FrameParams {
     uint32_t npt;       // padded pixels per sample plane: tilesX*tilesY*64
     uint32_t S;         // samples per frame = ssq*ssq
     int32_t shadowEarlyOut;   // RGB shadow rays stop at the first hit that already proves occlusion
+    int32_t spectralPdfAsWritten;   // Spectral: area pdf without the light-selection probability
     // Tile-split sharding: this context renders only the 8x8 tiles whose row-major
     // index i satisfies i % tileStride == tileOffset (all tiles when stride is 1).
     uint32_t tileOffset, tileStride;
@@ -946,7 +947,7 @@ __global__ __launch_bounds__(kBlock) void k_shade_spectral(SceneView sc, FramePa
                         if (info.isPrimitive) {
                             wBrdf = 1.0f;
                         } else {
-                            float pdfArea = 1.0f / info.area / (float)sc.lightSourcesCount / (float)info.modelLightCounts;
+                            float pdfArea = fp.spectralPdfAsWritten ? 1.0f / info.area : 1.0f / info.area / (float)sc.lightSourcesCount / (float)info.modelLightCounts;
                             float pdfNee = pdfArea * (info.t * info.t) / fmax_(abs_(dot(V, N)), kMinDenominator);
                             wBrdf = (prevBrdfPdf * prevBrdfPdf) / fmax_(prevBrdfPdf * prevBrdfPdf + pdfNee * pdfNee, kMinDenominator);
                         }
@@ -1003,7 +1004,7 @@ __global__ __launch_bounds__(kBlock) void k_shade_spectral(SceneView sc, FramePa
                             V3 sdir = normalize(toLight);
                             float distToLight = length(p - so);
                             float cosTheta = fmax_(dot(N, sdir), 0.0f);
-                            float pdf = 1.0f / area / (float)sc.lightSourcesCount / lightTriangleCount;
+                            float pdf = fp.spectralPdfAsWritten ? 1.0f / area : 1.0f / area / (float)sc.lightSourcesCount / lightTriangleCount;
                             V3 Hd = normalize(V + sdir);
                             float NoLd = clamp_(dot(N, sdir), 0.0f, 1.0f);
                             float NoHd = clamp_(dot(N, Hd), 0.0f, 1.0f);
@@ -1192,6 +1193,7 @@ struct rt_ctx {
     int maxTreeDepth = 0;
     bool hasAlphaTest = false;
     bool shadowEarlyOut = true;
+    bool spectralPdfAsWritten = false;
     uint32_t tileOffset = 0, tileStride = 1;
     bool planesInner = true;   // tile-major path order inside a batch
     int refillLanes = 32;   // idle lanes that trigger a refill for stages > 0
@@ -1838,6 +1840,7 @@ int rt_set_frame(rt_ctx *ctx, const rt_camera *cam, const float sky_linear[3], i
     fp.npt = (uint32_t)fp.tilesX * (uint32_t)fp.tilesY * 64u;
     fp.S = (uint32_t)fp.ssq * (uint32_t)fp.ssq;
     fp.shadowEarlyOut = (ctx->shadowEarlyOut && type == RT_TYPE_RGB) ? 1 : 0;
+    fp.spectralPdfAsWritten = ctx->spectralPdfAsWritten ? 1 : 0;
     fp.tileOffset = ctx->tileOffset;
     fp.tileStride = ctx->tileStride;
     ctx->type = type;
@@ -2074,6 +2077,10 @@ int rt_set_option(rt_ctx *ctx, int option, int value) {
         case RT_OPT_INNER_SHARE:
             if (value < 1 || value > 64) return RT_ERR_INVALID;
             ctx->innerShare = value;
+            return RT_OK;
+        case RT_OPT_SPECTRAL_PDF_AS_WRITTEN:
+            ctx->spectralPdfAsWritten = value != 0;
+            ctx->fp.spectralPdfAsWritten = value != 0 ? 1 : 0;
             return RT_OK;
         case RT_OPT_TILE_MAJOR:
             ctx->planesInner = value != 0;

@@ -415,3 +415,23 @@ def test_cpp_example_program_renders_the_same_picture(tmp_path):
     finally:
         b.close()
     assert np.array_equal(np.asarray(Image.open(out)), want)
+
+
+@pytest.mark.parametrize("name,kw", [("mixed", dict(nu=96, nv=16)), ("prism", {})])
+def test_spectral_area_pdf_as_written(backend, name, kw):
+    """The other reading of the Spectral shader's light pdf (1/area, without the light-selection
+    probability): darker direct light than the default reading, and the same on both sides."""
+    W, H, frames = 64, 48, 2
+    scene, cam = _setup(backend, name, kw, W, H, 4, 4, capi.RT_TYPE_SPECTRAL)
+    backend.render(first_frame=1, n_frames=frames, stride=1)
+    default, _ = backend.readback()
+    try:
+        backend.set_option(capi.RT_OPT_SPECTRAL_PDF_AS_WRITTEN, 1)
+        backend.reset_accum()
+        backend.render(first_frame=1, n_frames=frames, stride=1)
+        got, _ = backend.readback()
+    finally:
+        backend.set_option(capi.RT_OPT_SPECTRAL_PDF_AS_WRITTEN, 0)
+    want, _ = OracleScene(scene).render(cam, capi.RT_TYPE_SPECTRAL, 1, frames, 1, spectral_pdf_as_written=True)
+    assert np.array_equal(got, want, equal_nan=True)
+    assert not np.array_equal(got, default)
