@@ -83,7 +83,7 @@ int main(int argc, char **argv) {
         scene.submit();   // submit scene to the GPU
     }
 
-    for (int f = 0; f < frames; ++f) rayEngine.render();   // accumulate
+    rayEngine.render(static_cast<u32>(frames));   // accumulate
 
     rt_ctx *ctx = rayEngine.getRayTracer().backend();
     std::vector<uint8_t> rgba8(static_cast<size_t>(width) * height * 4);

@@ -16,4 +16,4 @@ void RayEngine::changeResolution(glm::ivec2 resolution) {
     m_camera.resolution = resolution;
 }
 
-void RayEngine::render() { m_rayTracer.renderToTexture(m_camera, m_rayScene); }
+void RayEngine::render(u32 frames) { m_rayTracer.renderToTexture(m_camera, m_rayScene, frames); }

@@ -17,8 +17,9 @@ public:
 
     bool initialize(const RayCamera &camera, RayTracer::Type raytracerType, int device = 0);
     void changeResolution(glm::ivec2 resolution);
-    // One progressive frame (what the reference's full-screen draw computes).
-    void render();
+    // One progressive frame (what the reference's full-screen draw computes), or
+    // `frames` of them traced as one batch.
+    void render(u32 frames = 1);
 
     RayScene &getScene() { return m_rayScene; }
     RayTracer &getRayTracer() { return m_rayTracer; }

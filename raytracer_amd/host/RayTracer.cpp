@@ -25,8 +25,9 @@ bool RayTracer::initialize(glm::ivec2 resolution, Type type) {
     return true;
 }
 
-// Uniform set of reference src/RayTracer.cpp:1436-1451, then one frame.
-void RayTracer::renderToTexture(const RayCamera &camera, const RayScene &scene) {
+// Uniform set of reference src/RayTracer.cpp:1436-1451, then the frames.
+void RayTracer::renderToTexture(const RayCamera &camera, const RayScene &scene, u32 frames) {
+    if (frames == 0) return;
     scene.bind();
 
     rt_camera cam;
@@ -46,11 +47,11 @@ void RayTracer::renderToTexture(const RayCamera &camera, const RayScene &scene) 
     const float skyv[3] = {sky.x, sky.y, sky.z};
     int rc = rt_set_frame(m_ctx, &cam, skyv, m_type == Type::RGB ? RT_TYPE_RGB : RT_TYPE_SPECTRAL);
     ASSERT(rc == RT_OK);
-    rc = rt_render(m_ctx, m_frameCount, 1, 1);
+    rc = rt_render(m_ctx, m_frameCount, frames, 1);
     ASSERT(rc == RT_OK);
 
-    m_frameIndex = !m_frameIndex;
-    ++m_frameCount;
+    if (frames & 1u) m_frameIndex = !m_frameIndex;
+    m_frameCount += frames;
 }
 
 // Like the reference (src/RayTracer.cpp:1454-1465) this re-creates the frame

@@ -41,8 +41,10 @@ public:
     // Creates the backend context and the accumulation frame.  false when no
     // device/back end is available (the reference returns false on shader errors).
     bool initialize(glm::ivec2 resolution, Type type);
-    // Sets the per-frame uniforms and queues one progressive frame.
-    void renderToTexture(const RayCamera &camera, const RayScene &scene);
+    // Sets the per-frame uniforms and queues `frames` progressive frames (the
+    // reference draws one per call; several frames in one call are traced as one
+    // batch and give the same accumulated image as that many single calls).
+    void renderToTexture(const RayCamera &camera, const RayScene &scene, u32 frames = 1);
     void changeResolution(glm::ivec2 resolution);
     void reset();
 

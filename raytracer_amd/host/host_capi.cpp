@@ -326,7 +326,7 @@ rth_engine *rth_engine_create(const char *scene_name, const int32_t *iparams, in
 
 int rth_engine_render(rth_engine *e, int frames) {
     if (e == nullptr || frames < 0) return RT_ERR_INVALID;
-    for (int i = 0; i < frames; ++i) e->engine.render();
+    e->engine.render(static_cast<u32>(frames));
     e->frames += frames;
     return RT_OK;
 }

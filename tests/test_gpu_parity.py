@@ -227,7 +227,8 @@ def test_ray_engine_api_progressive_mean():
     pos = (C.c_float * 3)(0.0, 1.0, -2.2)
     eng = capi.host.rth_engine_create(b"cornell_quads", None, 0, pos, 90.0, 0.0, 50.0, W, H, 3, 4, capi.RT_TYPE_RGB, 0)
     assert eng
-    assert capi.host.rth_engine_render(eng, 3) == 0
+    assert capi.host.rth_engine_render(eng, 1) == 0     # one frame per call, as the reference's loop does
+    assert capi.host.rth_engine_render(eng, 2) == 0     # and two frames traced as one batch
     out = np.empty((H, W, 4), np.float32)
     assert capi.host.rth_engine_frame(eng, out.ctypes.data_as(C.c_void_p), out.size) == 3
     capi.host.rth_engine_free(eng)
