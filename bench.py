@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--tex-size", type=int, default=0, help="texture edge of the textured scenes (0 = scene default)")
     ap.add_argument("--bvh", choices=["reference", "sah"], default="reference",
                     help="tree builder: the reference's median split (default; the only mode whose traversal is the reference's) or the opt-in SAH build")
+    ap.add_argument("--wide", action="store_true", help="opt-in four-wide tree (RT_OPT_WIDE_BVH): closest hits, not the reference's visiting order")
     ap.add_argument("--scene", default="cornell_knot")
     ap.add_argument("--spectral", action="store_true")
     ap.add_argument("--shard", choices=["sample", "tile"], default="sample",
@@ -80,6 +81,9 @@ def main():
     cam = capi.make_camera(width=args.width, height=args.height, bounces=args.bounces, ray_per_pixel=1)
 
     be = capi.Backend(local_rank)
+    if args.wide:
+        be.set_option(capi.RT_OPT_WIDE_BVH, 1)
+    wide = args.wide or os.environ.get("RT_WIDE_BVH", "0") not in ("", "0")
     be.upload_scene(scene)
     be.resize(args.width, args.height)
     # The sum buffer is a torch tensor so RCCL can reduce it in place.
@@ -177,7 +181,8 @@ def main():
             "config": {
                 "workload": f"{args.scene} ({'procedural dragon-class mesh, ' if 'knot' in args.scene else ''}{triangles} triangles in {scene.models_count} models), "
                             f"{args.width}x{args.height}, {args.spp} spp per {'image' if tile_split else 'GPU'} per step, primary+{args.bounces} bounces, "
-                            f"{'Spectral' if args.spectral else 'RGB'} NEE+MIS" + (", opt-in SAH trees (not the reference's traversal order)" if args.bvh == "sah" else ""),
+                            f"{'Spectral' if args.spectral else 'RGB'} NEE+MIS" + (", opt-in SAH trees (not the reference's traversal order)" if args.bvh == "sah" else "")
+                            + (", opt-in four-wide tree (closest hits, not the reference's traversal order)" if wide else ""),
                 "sharding": (("tile-split 8x8 tiles" if tile_split else "sample-split frames") + f", scene replicated, {'RCCL' if args.dist_backend == 'nccl' else args.dist_backend} sum-reduce of the fp32 accumulation buffer") if distributed else "single GPU",
                 "rays_per_camera_sample": round(total_rays / max(total_samples, 1), 4),
             },
@@ -218,7 +223,7 @@ def measured_traffic(args):
     Counters cannot be read from inside this process, so the figure is the one measured with rocprofv3
     on this same command; it is only reported for the default workload it was measured on."""
     path = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-    default = (args.scene == "cornell_knot" and args.bvh == "reference" and not args.spectral and (args.width, args.height, args.spp, args.bounces, args.nu, args.nv) == (1920, 1080, 64, 4, 2048, 213))
+    default = (args.scene == "cornell_knot" and args.bvh == "reference" and not args.wide and not args.spectral and (args.width, args.height, args.spp, args.bounces, args.nu, args.nv) == (1920, 1080, 64, 4, 2048, 213))
     if not default or not os.path.exists(path):
         return None, "not measured for this workload"
     with open(path) as f:

@@ -65,6 +65,7 @@ typedef struct rt_stats {
     double trace_ms;        /* device time in the traversal kernel (HIP events) */
     double total_ms;        /* device time of rt_render as a whole */
     uint64_t trace_launches;
+    uint64_t max_stack;     /* most traversal-stack entries any ray held (only if counters enabled) */
 } rt_stats;
 
 /* Creates a context on HIP device `device`.  Replaces the GL context +
@@ -153,7 +154,8 @@ int rt_reset_stats(rt_ctx *ctx);
 /* Enables per-ray node/triangle visit counting (slower; off by default). */
 int rt_set_counters(rt_ctx *ctx, int enabled);
 
-/* Switches (no reference counterpart).  Only RT_OPT_SPECTRAL_PDF_AS_WRITTEN changes output values.
+/* Switches (no reference counterpart).  Only RT_OPT_SPECTRAL_PDF_AS_WRITTEN and RT_OPT_WIDE_BVH
+ * can change output values.
  *   RT_OPT_SHADOW_EARLY_OUT  RGB shadow rays stop at the first hit nearer than
  *                            distToLight - 1e-4: such a hit already fails the reference's
  *                            visibility test (src/RayTracer.cpp:439), so finishing the
@@ -174,9 +176,16 @@ int rt_set_counters(rt_ctx *ctx, int enabled);
  *                            lightTriangles as in the RGB integrator (src/RayTracer.cpp:363-365,
  *                            427).  1: pdf = 1/area, literally as src/RayTracer.cpp:1082,1165 write it.
  *   RT_OPT_TILE_MAJOR        order of the paths inside a batch: 1 (default) keeps all sample
- *                            planes of an 8x8 pixel tile adjacent, 0 orders plane by plane */
+ *                            planes of an 8x8 pixel tile adjacent, 0 orders plane by plane
+ *   RT_OPT_WIDE_BVH          1: rays walk a four-wide tree with 8-bit child boxes that the library
+ *                            derives from the uploaded binary tree (same leaves, same triangles).
+ *                            Every ray still gets its closest hit, but the trees are not visited
+ *                            in the order of hitModel (src/RayScene.cpp:681-736), so where two
+ *                            triangles are hit at the same distance (shared edges, coplanar
+ *                            duplicates) the other one may win.  Default 0: the reference's order,
+ *                            bit-identical hits.  Rebuilds the derived tree of a committed scene. */
 enum { RT_OPT_SHADOW_EARLY_OUT = 1, RT_OPT_REFILL_LANES = 2, RT_OPT_INNER_SHARE = 3, RT_OPT_MAX_PATHS = 4, RT_OPT_TILE_MAJOR = 5,
-       RT_OPT_SPECTRAL_PDF_AS_WRITTEN = 6 };
+       RT_OPT_SPECTRAL_PDF_AS_WRITTEN = 6, RT_OPT_WIDE_BVH = 7 };
 int rt_set_option(rt_ctx *ctx, int option, int value);
 
 const char *rt_strerror(int status);

@@ -15,6 +15,7 @@ _LIB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib")
 RT_SLOT_OBJECTS, RT_SLOT_MATERIALS, RT_SLOT_MODEL_INFO, RT_SLOT_MODELS, RT_SLOT_TEXTURES = 1, 2, 3, 4, 5
 RT_TYPE_RGB, RT_TYPE_SPECTRAL = 0, 1
 RT_OPT_SHADOW_EARLY_OUT, RT_OPT_REFILL_LANES, RT_OPT_INNER_SHARE, RT_OPT_MAX_PATHS, RT_OPT_TILE_MAJOR, RT_OPT_SPECTRAL_PDF_AS_WRITTEN = 1, 2, 3, 4, 5, 6
+RT_OPT_WIDE_BVH = 7
 
 # Every symbol include/rt_hip.h declares.
 HIP_SYMBOLS = [
@@ -54,6 +55,7 @@ class RtStats(C.Structure):
         ("trace_ms", C.c_double),
         ("total_ms", C.c_double),
         ("trace_launches", C.c_uint64),
+        ("max_stack", C.c_uint64),
     ]
 
 

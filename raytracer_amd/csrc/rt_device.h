@@ -25,6 +25,18 @@ struct __attribute__((aligned(64))) PackedNode {
 };
 static_assert(sizeof(PackedNode) == 64, "inner node must be one 64-byte line");
 
+// Optional four-wide node derived from the same tree at commit time (one 64-byte line): the
+// children's boxes are stored as 8-bit offsets from `o` in units of `s` per axis, rounded outwards,
+// so plane = o + q*s never cuts into the box it stands for.  Child references as above; an unused
+// slot holds the inverted box lo=255, hi=0 and the reference ~0 (a leaf without triangles).
+struct __attribute__((aligned(64))) WideNode {
+    float o[3]; int32_t c0;
+    float s[3]; int32_t c1;
+    uint32_t lo[3]; int32_t c2;    // byte k of lo[a] = lower plane of child k on axis a
+    uint32_t hi[3]; int32_t c3;
+};
+static_assert(sizeof(WideNode) == 64, "wide node must be one 64-byte line");
+
 struct __attribute__((aligned(16))) PackedTri {
     float a[3];  int32_t material;   // vertex A,   scene-wide material index
     float ab[3]; int32_t model;      // B - A,      model slot | flags (kTriAlphaTest)
@@ -35,7 +47,7 @@ constexpr int32_t kTriAlphaTest = 1 << 30;  // triangle needs the alpha-cut text
 constexpr int32_t kTriModelMask = (1 << 30) - 1;
 
 struct ModelDesc {
-    int32_t rootRef;            // child reference of node 0
+    int32_t rootRef;            // child reference of node 0 (in the four-wide tree when that mode is on)
     int32_t nodesCount, identifiersCount, lightSourcesCount;
     int32_t lightBase;          // word offset of the light identifiers (the info stream's location)
     int32_t nodeBase;           // word offset of node 0
@@ -48,6 +60,7 @@ struct ModelDesc {
 struct SceneView {
     const float *objects, *materials, *modelInfo, *models, *textures;
     const PackedNode *nodes;
+    const WideNode *wnodes;     // four-wide tree, null unless that mode is on
     const PackedTri *tris;
     const ModelDesc *modelDesc;
     int32_t objectCount, modelsCount, lightSourcesCount;

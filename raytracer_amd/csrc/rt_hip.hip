@@ -48,7 +48,17 @@ namespace {
 #ifndef RT_WALPHA
 #define RT_WALPHA 6   // alpha-cut variants: 80 VGPRs; at 7 waves/SIMD (72) they spill inside the main loop
 #endif
+#ifndef RT_WWIDE
+#define RT_WWIDE 7     // waves/SIMD of the four-wide variants (72 VGPRs with 40 B of spills: +4 % over 6 waves without)
+#endif
+#ifndef RT_WWIDE_ALPHA
+#define RT_WWIDE_ALPHA 5
+#endif
 constexpr int kStackDepth = 32;      // int stack[32], src/RayScene.cpp:682
+#ifndef RT_WSTACK
+#define RT_WSTACK 16
+#endif
+constexpr int kWideStack = RT_WSTACK;   // LDS stack entries of the four-wide variants; deeper entries go to memory
 constexpr int kBlock = 256;
 constexpr int kMaxBounces = 62;      // stages kept on the device
 // Default ceiling of paths in flight per batch (~190 B of device memory each).  Every kernel of
@@ -121,7 +131,10 @@ struct PathBuffers {
     uint32_t *qShadow;   // [kSubQueues * subCap]
     uint32_t subCap;     // capacity of one sub-queue
     Stage *stages;       // [kMaxBounces + 2]
-    unsigned long long *counters;  // [8]: 0 rays, 1 nodeVisits, 2 triTests, 3 shadedHits
+    unsigned long long *counters;  // [8]: 0 rays, 1 nodeVisits, 2 triTests, 3 shadedHits, 4 deepest traversal stack
+    // Four-wide traversal only: stack entries beyond the LDS part, [wave][overflowDepth][64].
+    int32_t *overflow;
+    uint32_t overflowDepth;
 };
 
 __device__ __forceinline__ uint32_t laneId() { return threadIdx.x & 63u; }
@@ -219,6 +232,33 @@ __device__ __forceinline__ float slabDistance(V3 bmin, V3 bmax, V3 ro, V3 inv, f
     float farD = fmin3_(t2.x, t2.y, t2.z);
     // The reference returns early when nearD > t; as a select it is the same value without a branch.
     return (!(nearD > t) && farD >= nearD && farD > 0.0f) ? nearD : 1e20f;
+}
+
+// Byte k of a word as float (v_cvt_f32_ubyteK).
+template <int K> __device__ __forceinline__ float byteAsFloat(uint32_t w) { return (float)((w >> (8 * K)) & 0xffu); }
+
+// Entry distance of child K of a four-wide node, 1e20 when the ray misses it or enters it at or
+// beyond `t`.  nx..fz are the words holding the planes the ray meets first / last on each axis,
+// (sx, bx) map a plane number q to the ray parameter q*sx + bx.
+typedef float float2v __attribute__((ext_vector_type(2)));
+template <int K>
+__device__ __forceinline__ float wideChildDistance(uint32_t nx, uint32_t ny, uint32_t nz, uint32_t fx, uint32_t fy, uint32_t fz,
+                                                   float2v sx, float2v sy, float2v sz, float2v bx, float2v by, float2v bz, float t) {
+    // (near, far) of one axis as one packed multiply-add
+    const float2v tx = __builtin_elementwise_fma((float2v){byteAsFloat<K>(nx), byteAsFloat<K>(fx)}, sx, bx);
+    const float2v ty = __builtin_elementwise_fma((float2v){byteAsFloat<K>(ny), byteAsFloat<K>(fy)}, sy, by);
+    const float2v tz = __builtin_elementwise_fma((float2v){byteAsFloat<K>(nz), byteAsFloat<K>(fz)}, sz, bz);
+    const float nearD = fmax3_(tx.x, ty.x, tz.x);
+    const float farD = fmin3_(tx.y, ty.y, tz.y);
+    return (nearD < t && farD >= nearD && farD > 0.0f) ? nearD : 1e20f;
+}
+
+// Orders two (distance, reference) pairs by distance.
+__device__ __forceinline__ void orderPair(float &da, int32_t &ca, float &db, int32_t &cb) {
+    const bool swap = db < da;
+    const float dLo = swap ? db : da, dHi = swap ? da : db;
+    const int32_t cLo = swap ? cb : ca, cHi = swap ? ca : cb;
+    da = dLo; db = dHi; ca = cLo; cb = cHi;
 }
 
 // Alpha-cut rejection inside hitTriangle (src/RayScene.cpp:547-577).  Only
@@ -376,8 +416,13 @@ __device__ __forceinline__ void intersectPrimitives(const SceneView &sc, LaneRay
 // keeps whole 64-ray packets together, which is what coherent camera rays want;
 // incoherent rays run best around 32).  The traversal stack of each lane lives
 // in LDS ([entry][lane], conflict free).
-template <bool COUNT, int STACK, bool ALPHA, bool PRIMS, bool ROOTS>
-__global__ __launch_bounds__(kBlock, (STACK <= 20 ? (ALPHA ? RT_WALPHA : PRIMS ? 7 : RT_W20) : STACK <= 24 ? (ALPHA ? (RT_WALPHA < 6 ? RT_WALPHA : 6) : 6) : 5)) void k_trace(SceneView sc, PathBuffers pb, int extParity, int stage, int refillLanes, int innerShare) {
+//
+// WIDE variants walk the four-wide tree instead: half as many dependent node loads per ray.  They
+// find the closest hit of every model like the others, but not by the reference's visiting order,
+// so the winner among hits at (nearly) the same distance can differ from the reference's.
+template <bool COUNT, int STACK, bool ALPHA, bool PRIMS, bool ROOTS, bool WIDE>
+__global__ __launch_bounds__(kBlock, WIDE ? (ALPHA ? RT_WWIDE_ALPHA : RT_WWIDE)
+                                          : (STACK <= 20 ? (ALPHA ? RT_WALPHA : PRIMS ? 7 : RT_W20) : STACK <= 24 ? (ALPHA ? (RT_WALPHA < 6 ? RT_WALPHA : 6) : 6) : 5)) void k_trace(SceneView sc, PathBuffers pb, int extParity, int stage, int refillLanes, int innerShare) {
     __shared__ int32_t stackLds[kBlock / 64][STACK][64];
     // ROOTS variants (scenes with more than two models): the models' root references sit in LDS.
     // With one or two models the descriptor loads hit the L1 and the plain variant is faster
@@ -404,12 +449,20 @@ __global__ __launch_bounds__(kBlock, (STACK <= 20 ? (ALPHA ? RT_WALPHA : PRIMS ?
     int source = firstSource + (int)(waveId % (uint32_t)numSources);
     bool drained = false;    // every source has been seen empty
 
-    uint32_t cntNodes = 0, cntTris = 0;
+    uint32_t cntNodes = 0, cntTris = 0, maxSp = 0;
     bool active = false;
     LaneRay r;
     r.slot = 0;
+    // Four-wide variants: this lane's column of the stack part that does not fit in LDS.
+    int32_t *overflow = WIDE ? pb.overflow + (size_t)waveId * pb.overflowDepth * 64 + lane : nullptr;
+    auto pushWide = [&](int32_t ref) {
+        if (r.sp < STACK) stack[r.sp][lane] = ref;
+        else overflow[(size_t)(r.sp - STACK) * 64] = ref;
+        r.sp++;
+    };
 
     for (;;) {
+        if (COUNT && active) maxSp = max(maxSp, (uint32_t)r.sp);
         const unsigned long long idleMask = __ballot(!active);
         const int nIdle = __popcll(idleMask);
         if (!drained && nIdle >= refillLanes) {
@@ -453,7 +506,15 @@ __global__ __launch_bounds__(kBlock, (STACK <= 20 ? (ALPHA ? RT_WALPHA : PRIMS ?
                     const float4 r0 = rp[0], r1 = rp[1];
                     r.ro = v3(r0.x, r0.y, r0.z);
                     r.rd = v3(r1.x, r1.y, r1.z);
-                    r.inv = v3(1.0f / r.rd.x, 1.0f / r.rd.y, 1.0f / r.rd.z);
+                    if (WIDE) {
+                        // Only box tests use inv here, and the boxes carry a margin: the one-instruction
+                        // reciprocal will do.  Plane numbers are scaled by inv, so keep it finite (a
+                        // direction component of zero then behaves like a very small one of the same sign).
+                        r.inv = v3(__builtin_amdgcn_rcpf(r.rd.x), __builtin_amdgcn_rcpf(r.rd.y), __builtin_amdgcn_rcpf(r.rd.z));
+                        r.inv = v3(fminI_(fmaxI_(r.inv.x, -1e18f), 1e18f), fminI_(fmaxI_(r.inv.y, -1e18f), 1e18f), fminI_(fmaxI_(r.inv.z, -1e18f), 1e18f));
+                    } else {
+                        r.inv = v3(1.0f / r.rd.x, 1.0f / r.rd.y, 1.0f / r.rd.z);
+                    }
                     r.tStop = r1.w;
                     if (PRIMS) {
                         intersectPrimitives<COUNT>(sc, r, cntTris);
@@ -511,7 +572,41 @@ __global__ __launch_bounds__(kBlock, (STACK <= 20 ? (ALPHA ? RT_WALPHA : PRIMS ?
         const bool innerPhase = nInner * 64 >= nActive * innerShare;
         bool pop = false, occluded = false;
         if (innerPhase) {
-            if (onInner) {
+            if (WIDE) {
+                if (onInner) {
+                    if (COUNT) cntNodes++;
+                    const float4 *np = reinterpret_cast<const float4 *>(&sc.wnodes[r.ref]);
+                    const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+                    const float sx1 = n1.x * r.inv.x, sy1 = n1.y * r.inv.y, sz1 = n1.z * r.inv.z;
+                    const float bx1 = (n0.x - r.ro.x) * r.inv.x, by1 = (n0.y - r.ro.y) * r.inv.y, bz1 = (n0.z - r.ro.z) * r.inv.z;
+                    const float2v sx = {sx1, sx1}, sy = {sy1, sy1}, sz = {sz1, sz1}, bx = {bx1, bx1}, by = {by1, by1}, bz = {bz1, bz1};
+                    const uint32_t lox = __float_as_uint(n2.x), loy = __float_as_uint(n2.y), loz = __float_as_uint(n2.z);
+                    const uint32_t hix = __float_as_uint(n3.x), hiy = __float_as_uint(n3.y), hiz = __float_as_uint(n3.z);
+                    const bool ngx = r.inv.x < 0.0f, ngy = r.inv.y < 0.0f, ngz = r.inv.z < 0.0f;
+                    const uint32_t nx = ngx ? hix : lox, fx = ngx ? lox : hix;
+                    const uint32_t ny = ngy ? hiy : loy, fy = ngy ? loy : hiy;
+                    const uint32_t nz = ngz ? hiz : loz, fz = ngz ? loz : hiz;
+                    float d0 = wideChildDistance<0>(nx, ny, nz, fx, fy, fz, sx, sy, sz, bx, by, bz, r.tModel);
+                    float d1 = wideChildDistance<1>(nx, ny, nz, fx, fy, fz, sx, sy, sz, bx, by, bz, r.tModel);
+                    float d2 = wideChildDistance<2>(nx, ny, nz, fx, fy, fz, sx, sy, sz, bx, by, bz, r.tModel);
+                    float d3 = wideChildDistance<3>(nx, ny, nz, fx, fy, fz, sx, sy, sz, bx, by, bz, r.tModel);
+                    int32_t c0 = __float_as_int(n0.w), c1 = __float_as_int(n1.w), c2 = __float_as_int(n2.w), c3 = __float_as_int(n3.w);
+                    orderPair(d0, c0, d1, c1);
+                    orderPair(d2, c2, d3, c3);
+                    orderPair(d0, c0, d2, c2);
+                    orderPair(d1, c1, d3, c3);
+                    orderPair(d1, c1, d2, c2);
+                    // Nearest child next, the others on the stack with the farthest at the bottom.
+                    if (d0 < 1e20f) {
+                        if (d3 < 1e20f) { pushWide(c3); }
+                        if (d2 < 1e20f) { pushWide(c2); }
+                        if (d1 < 1e20f) { pushWide(c1); }
+                        r.ref = c0;
+                    } else {
+                        pop = true;
+                    }
+                }
+            } else if (onInner) {
                 if (COUNT) cntNodes++;
                 const float4 *np = reinterpret_cast<const float4 *>(&sc.nodes[r.ref]);
                 const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
@@ -538,37 +633,66 @@ __global__ __launch_bounds__(kBlock, (STACK <= 20 ? (ALPHA ? RT_WALPHA : PRIMS ?
             const uint32_t code = ~(uint32_t)r.ref;
             const uint32_t first = code >> 2, ntri = code & 3u;
             bool parked = false;
-            for (uint32_t k = ALPHA ? r.resume : 0u; k < ntri; ++k) {
+            // Möller–Trumbore as hitTriangle writes it (src/RayScene.cpp:510-545); returns true when the
+            // hit waits for its alpha-cut lookup.
+            auto testTriangle = [&](uint32_t ti, const float4 &q0, const float4 &q1, const float4 &q2) -> bool {
                 if (COUNT) cntTris++;
-                const uint32_t ti = first + k;
-                const float4 *tp = reinterpret_cast<const float4 *>(&sc.tris[ti]);
-                const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
-                pinLoaded(q0, q1, q2);   // all three in one round trip, before the determinant test
                 const V3 A = v3(q0.x, q0.y, q0.z), ab = v3(q1.x, q1.y, q1.z), ac = v3(q2.x, q2.y, q2.z);
                 const V3 nrm = cross(ab, ac);
                 const float det = -dot(r.rd, nrm);
-                if (abs_(det) < 1e-8f) continue;
+                if (abs_(det) < 1e-8f) return false;
                 const V3 ao = r.ro - A;
                 const V3 dao = cross(ao, r.rd);
                 const float invDet = 1.0f / det;
                 const float t = dot(ao, nrm) * invDet;
-                if (t < 0.0f || t > r.maxT || t >= r.tModel) continue;
+                if (t < 0.0f || t > r.maxT || t >= r.tModel) return false;
                 const float u = dot(ac, dao) * invDet;
                 const float v = -dot(ab, dao) * invDet;
-                if (u < 0.0f || v < 0.0f || u + v > 1.0f) continue;
+                if (u < 0.0f || v < 0.0f || u + v > 1.0f) return false;
                 if (ALPHA && (__float_as_int(q1.w) & kTriAlphaTest)) {
                     r.pendT = t;
                     r.pendU = u;
                     r.pendV = v;
                     r.pendTri = ti;
-                    parked = true;
-                    break;
+                    return true;
                 }
                 r.tModel = t;
                 r.maxT = t;
                 r.mBest = ti;
                 r.mU = u;
                 r.mV = v;
+                return false;
+            };
+            if (WIDE && !ALPHA) {
+                // The usual leaf holds one or two triangles: fetch both in one round trip (the binary
+                // variants have no registers to spare for this: -10 % there, +2 % here).
+                const float4 *tp = reinterpret_cast<const float4 *>(&sc.tris[first]);
+                if (ntri > 0u) {
+                    const bool two = ntri > 1u;
+                    const float4 a0 = tp[0], a1 = tp[1], a2 = tp[2];
+                    float4 b0 = a0, b1 = a1, b2 = a2;
+                    if (two) { b0 = tp[3]; b1 = tp[4]; b2 = tp[5]; }
+                    pinLoaded(a0, a1, a2);
+                    pinLoaded(b0, b1, b2);
+                    testTriangle(first, a0, a1, a2);
+                    if (two) testTriangle(first + 1u, b0, b1, b2);
+                    for (uint32_t k = 2u; k < ntri; ++k) {
+                        const float4 q0 = tp[3 * k], q1 = tp[3 * k + 1], q2 = tp[3 * k + 2];
+                        pinLoaded(q0, q1, q2);
+                        testTriangle(first + k, q0, q1, q2);
+                    }
+                }
+            } else {
+                for (uint32_t k = ALPHA ? r.resume : 0u; k < ntri; ++k) {
+                    const uint32_t ti = first + k;
+                    const float4 *tp = reinterpret_cast<const float4 *>(&sc.tris[ti]);
+                    const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
+                    pinLoaded(q0, q1, q2);   // all three in one round trip, before the determinant test
+                    if (testTriangle(ti, q0, q1, q2)) {
+                        parked = true;
+                        break;
+                    }
+                }
             }
             if (!parked) {
                 if (ALPHA) r.resume = 0u;
@@ -578,7 +702,9 @@ __global__ __launch_bounds__(kBlock, (STACK <= 20 ? (ALPHA ? RT_WALPHA : PRIMS ?
         }
         if (pop) {
             if (r.sp > 0 && !occluded) {
-                r.ref = stack[--r.sp][lane];
+                --r.sp;
+                if (WIDE && r.sp >= STACK) r.ref = overflow[(size_t)(r.sp - STACK) * 64];
+                else r.ref = stack[r.sp][lane];
             } else {
                 if (r.mBest != kMiss) {
                     r.closest = r.tModel;
@@ -615,10 +741,12 @@ __global__ __launch_bounds__(kBlock, (STACK <= 20 ? (ALPHA ? RT_WALPHA : PRIMS ?
         for (int off = 32; off > 0; off >>= 1) {
             cntNodes += __shfl_down(cntNodes, off);
             cntTris += __shfl_down(cntTris, off);
+            maxSp = max(maxSp, (uint32_t)__shfl_down(maxSp, off));
         }
         if (lane == 0) {
             atomicAdd(&pb.counters[1], (unsigned long long)cntNodes);
             atomicAdd(&pb.counters[2], (unsigned long long)cntTris);
+            atomicMax(&pb.counters[4], (unsigned long long)maxSp);
         }
     }
 }
@@ -1170,6 +1298,9 @@ struct rt_ctx {
     int objectCount = 0, modelsCount = 0, lightSourcesCount = 0;
     bool committed = false;
     PackedNode *dNodes = nullptr;
+    WideNode *dWNodes = nullptr;    // four-wide tree (wideBvh only)
+    bool wideBvh = false;
+    int wideStackNeed = 0;          // most stack entries a ray can hold in the four-wide tree
     PackedTri *dTris = nullptr;
     ModelDesc *dModelDesc = nullptr;
     std::vector<PackedTri> hTris;   // kept for id decoding in rt_trace_primary
@@ -1444,6 +1575,128 @@ int repackScene(rt_ctx *ctx, std::vector<PackedNode> &nodes, std::vector<PackedT
     return RT_OK;
 }
 
+// Four-wide tree of every model, collapsed from the binary tree of the model stream: a node
+// adopts the children of its child with the largest box until it has four (or only leaves are
+// left).  `descs` must have passed repackScene; rootRef is redirected to the new tree.
+int buildWideNodes(rt_ctx *ctx, std::vector<ModelDesc> &descs, std::vector<WideNode> &wnodes) {
+    const std::vector<float> &mdl = ctx->host[RT_SLOT_MODELS];
+    ctx->wideStackNeed = 0;
+    struct Item { int node; int32_t wide; int held; };   // binary node to expand, its slot, entries its ancestors keep stacked
+    std::vector<Item> todo;
+    for (ModelDesc &d : descs) {
+        if (d.nodesCount <= 0) continue;
+        auto word = [&](int n, int w) { return mdl[(size_t)d.nodeBase + (size_t)n * kNodeWords + w]; };
+        auto isLeaf = [&](int n) { return word(n, 8) != 0.0f; };
+        auto leafCount = [&](int n) { return f2i(word(n, 7)) - f2i(word(n, 6)); };
+        auto leafRef = [&](int n) { return ~(int32_t)((((uint32_t)(d.triBase + f2i(word(n, 6)))) << 2) | (uint32_t)leafCount(n)); };
+        auto area = [&](int n) {
+            const double ex = (double)word(n, 3) - word(n, 0), ey = (double)word(n, 4) - word(n, 1), ez = (double)word(n, 5) - word(n, 2);
+            return ex * ey + ey * ez + ez * ex;
+        };
+        if (isLeaf(0)) continue;   // rootRef already names the leaf
+        // Margin around every box for the rounding of the plane arithmetic on the device, whose
+        // operands are as large as the distance from the ray origin to the model: four units in the
+        // last place of the model's largest coordinate.
+        double reach = 0.0;
+        for (int w = 0; w < 6; ++w) reach = std::max(reach, (double)std::fabs(word(0, w)));
+        if (!(reach <= 1e15)) return RT_ERR_SCENE;
+        const double pad = std::ldexp(reach, -21);
+        d.rootRef = (int32_t)wnodes.size();
+        wnodes.emplace_back();
+        todo.push_back({0, d.rootRef, 0});
+        while (!todo.empty()) {
+            const Item it = todo.back();
+            todo.pop_back();
+            int kids[4] = {f2i(word(it.node, 6)), f2i(word(it.node, 7)), -1, -1};
+            int nk = 2;
+            while (nk < 4) {
+                int best = -1;
+                double bestArea = -1.0;
+                for (int i = 0; i < nk; ++i) {
+                    if (isLeaf(kids[i])) continue;
+                    const double a = area(kids[i]);
+                    if (best < 0 || a > bestArea) { best = i; bestArea = a; }
+                }
+                if (best < 0) break;
+                const int n = kids[best];
+                kids[best] = f2i(word(n, 6));
+                kids[nk++] = f2i(word(n, 7));
+            }
+            // Leaves without triangles need no slot.
+            int kept = 0;
+            for (int i = 0; i < nk; ++i)
+                if (!(isLeaf(kids[i]) && leafCount(kids[i]) == 0)) kids[kept++] = kids[i];
+            nk = kept;
+            for (int i = 0; i < nk; ++i)
+                for (int w = 0; w < 6; ++w) {
+                    const float x = word(kids[i], w);
+                    if (!(std::fabs(x) <= 1e15f)) return RT_ERR_SCENE;   // also catches NaN
+                }
+
+            WideNode wn{};
+            uint32_t lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+            for (int a = 0; a < 3; ++a) {
+                double lower = 0.0, upper = 0.0;
+                for (int i = 0; i < nk; ++i) {
+                    const double mn = word(kids[i], a), mx = word(kids[i], 3 + a);
+                    if (mn > mx) return RT_ERR_SCENE;
+                    if (i == 0 || mn < lower) lower = mn;
+                    if (i == 0 || mx > upper) upper = mx;
+                }
+                float o = (float)(lower - pad);
+                if ((double)o > lower - pad) o = std::nextafterf(o, -INFINITY);
+                const double extent = (upper + pad) - (double)o;
+                int e = -60;
+                if (extent > 0.0) e = std::max(-60, (int)std::ceil(std::log2(extent / 255.0)));
+                for (;; ++e) {
+                    const double step = std::ldexp(1.0, e);
+                    bool fits = true;
+                    uint32_t wlo = 0, whi = 0;
+                    for (int i = 0; i < 4 && fits; ++i) {
+                        uint32_t qlo = 255, qhi = 0;   // unused slot: inverted
+                        if (i < nk) {
+                            const double mn = (double)word(kids[i], a) - pad, mx = (double)word(kids[i], 3 + a) + pad;
+                            long ql = (long)std::floor((mn - (double)o) / step), qh = (long)std::ceil((mx - (double)o) / step);
+                            ql = std::max(0l, std::min(ql, 255l));
+                            while (ql > 0 && (double)o + (double)ql * step > mn) --ql;
+                            qh = std::max(qh, 0l);
+                            while (qh <= 255 && (double)o + (double)qh * step < mx) ++qh;
+                            if (qh > 255) { fits = false; break; }
+                            qlo = (uint32_t)ql;
+                            qhi = (uint32_t)qh;
+                        }
+                        wlo |= qlo << (8 * i);
+                        whi |= qhi << (8 * i);
+                    }
+                    if (fits) {
+                        wn.o[a] = o;
+                        wn.s[a] = (float)step;
+                        lo[a] = wlo;
+                        hi[a] = whi;
+                        break;
+                    }
+                }
+            }
+            for (int a = 0; a < 3; ++a) { wn.lo[a] = lo[a]; wn.hi[a] = hi[a]; }
+            int32_t refs[4] = {-1, -1, -1, -1};   // ~0: a leaf without triangles
+            const int held = it.held + std::max(nk - 1, 0);
+            ctx->wideStackNeed = std::max(ctx->wideStackNeed, held);
+            for (int i = 0; i < nk; ++i) {
+                if (isLeaf(kids[i])) {
+                    refs[i] = leafRef(kids[i]);
+                } else {
+                    refs[i] = (int32_t)wnodes.size();
+                    wnodes.emplace_back();
+                    todo.push_back({kids[i], refs[i], held});
+                }
+            }
+            wn.c0 = refs[0]; wn.c1 = refs[1]; wn.c2 = refs[2]; wn.c3 = refs[3];
+            wnodes[(size_t)it.wide] = wn;
+        }
+    }
+    return RT_OK;
+}
+
 // (Re)allocates every per-path buffer for `want` paths.  ctx->P is zero while the set is incomplete,
 // so a failed attempt can never leave a capacity that some buffer does not have.
 int allocPathBuffers(rt_ctx *ctx, uint64_t want64) {
@@ -1506,17 +1759,27 @@ void launchTrace(rt_ctx *ctx, int extParity, int stage) {
     // Kernel variant: visit counting, LDS stack depth (24 entries let 6 blocks share a
     // CU's LDS instead of 5), alpha-cut support only when some triangle needs it.
     using TraceFn = void (*)(SceneView, PathBuffers, int, int, int, int);
-#define RT_TRACE_ROW(C, S, R) {{k_trace<C, S, false, false, R>, k_trace<C, S, false, true, R>}, {k_trace<C, S, true, false, R>, k_trace<C, S, true, true, R>}}
+#define RT_TRACE_ROW(C, S, R) {{k_trace<C, S, false, false, R, false>, k_trace<C, S, false, true, R, false>}, {k_trace<C, S, true, false, R, false>, k_trace<C, S, true, true, R, false>}}
     static const TraceFn variants[2][3][2][2] = {{RT_TRACE_ROW(false, 20, false), RT_TRACE_ROW(false, 24, false), RT_TRACE_ROW(false, kStackDepth, false)},
                                                  {RT_TRACE_ROW(true, 20, false), RT_TRACE_ROW(true, 24, false), RT_TRACE_ROW(true, kStackDepth, false)}};
     static const TraceFn rootVariants[2][2][2] = {RT_TRACE_ROW(false, 20, true), RT_TRACE_ROW(false, 24, true)};
 #undef RT_TRACE_ROW
+#define RT_WIDE_ROW(C, R) {{k_trace<C, kWideStack, false, false, R, true>, k_trace<C, kWideStack, false, true, R, true>}, {k_trace<C, kWideStack, true, false, R, true>, k_trace<C, kWideStack, true, true, R, true>}}
+    static const TraceFn wideVariants[2][2][2][2] = {{RT_WIDE_ROW(false, false), RT_WIDE_ROW(false, true)}, {RT_WIDE_ROW(true, false), RT_WIDE_ROW(true, true)}};
+#undef RT_WIDE_ROW
     const int depthClass = ctx->maxTreeDepth <= 20 ? 0 : ctx->maxTreeDepth <= 24 ? 1 : 2;
     const bool prims = ctx->objectCount > 0;
-    const bool rootsInLds = ctx->modelsCount > 2 && depthClass < 2 && !ctx->countersOn;
-    const TraceFn fn = rootsInLds ? rootVariants[depthClass][ctx->hasAlphaTest ? 1 : 0][prims ? 1 : 0]
-                                  : variants[ctx->countersOn ? 1 : 0][depthClass][ctx->hasAlphaTest ? 1 : 0][prims ? 1 : 0];
-    const int wavesPerSimd = depthClass == 0 ? (ctx->hasAlphaTest ? RT_WALPHA : prims ? 7 : RT_W20) : depthClass == 1 ? (ctx->hasAlphaTest ? std::min(RT_WALPHA, 6) : 6) : 5;
+    TraceFn fn;
+    int wavesPerSimd;
+    if (ctx->wideBvh) {
+        fn = wideVariants[ctx->countersOn ? 1 : 0][ctx->modelsCount > 2 ? 1 : 0][ctx->hasAlphaTest ? 1 : 0][prims ? 1 : 0];
+        wavesPerSimd = ctx->hasAlphaTest ? RT_WWIDE_ALPHA : RT_WWIDE;
+    } else {
+        const bool rootsInLds = ctx->modelsCount > 2 && depthClass < 2 && !ctx->countersOn;
+        fn = rootsInLds ? rootVariants[depthClass][ctx->hasAlphaTest ? 1 : 0][prims ? 1 : 0]
+                        : variants[ctx->countersOn ? 1 : 0][depthClass][ctx->hasAlphaTest ? 1 : 0][prims ? 1 : 0];
+        wavesPerSimd = depthClass == 0 ? (ctx->hasAlphaTest ? RT_WALPHA : prims ? 7 : RT_W20) : depthClass == 1 ? (ctx->hasAlphaTest ? std::min(RT_WALPHA, 6) : 6) : 5;
+    }
     const int grid = ctx->numCUs * wavesPerSimd;
     hipLaunchKernelGGL(fn, dim3(grid), dim3(kBlock), 0, ctx->stream, ctx->view, ctx->pb, extParity, stage, refill, ctx->innerShare);
     if (e1) hipEventRecord(e1, ctx->stream);
@@ -1689,6 +1952,7 @@ int rt_create(rt_ctx **out, int device) {
         if (v > 0) ctx->maxPaths = (uint32_t)std::min<long>(v, 1l << 30);
     }
     if (const char *env = std::getenv("RT_TILE_MAJOR")) ctx->planesInner = std::atoi(env) != 0;
+    if (const char *env = std::getenv("RT_WIDE_BVH")) ctx->wideBvh = std::atoi(env) != 0;
     if (const char *env = std::getenv("RT_INNER_SHARE")) {
         int v = std::atoi(env);
         if (v >= 1 && v <= 64) ctx->innerShare = v;
@@ -1706,7 +1970,7 @@ void rt_destroy(rt_ctx *ctx) {
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
     for (float *p : ctx->dStream) if (p) hipFree(p);
-    void *owned[] = {ctx->dNodes, ctx->dTris, ctx->dModelDesc, ctx->accumExternal ? nullptr : (void *)ctx->dAccum, ctx->dPartial,
+    void *owned[] = {ctx->dNodes, ctx->dWNodes, ctx->pb.overflow, ctx->dTris, ctx->dModelDesc, ctx->accumExternal ? nullptr : (void *)ctx->dAccum, ctx->dPartial,
                      ctx->pb.rays, ctx->pb.hits, ctx->pb.stA, ctx->pb.stB, ctx->pb.neeA, ctx->pb.neeB, ctx->pb.neeC,
                      ctx->pb.qExt[0], ctx->pb.qExt[1], ctx->pb.qShadow, ctx->pb.stages, ctx->pb.counters};
     for (void *p : owned) if (p) hipFree(p);
@@ -1753,6 +2017,19 @@ int rt_commit_scene(rt_ctx *ctx, int objectCount, int modelsCount, int lightSour
         RT_HIP(hipMemcpy(ctx->dStream[s], padded.data(), padded.size() * sizeof(float), hipMemcpyHostToDevice));
         ctx->dStreamWords[s] = ctx->host[s].size();
     }
+    std::vector<WideNode> wnodes;
+    if (ctx->wideBvh) {
+        if ((rc = buildWideNodes(ctx, descs, wnodes)) != RT_OK) return rc;
+        if ((rc = devAlloc(ctx, &ctx->dWNodes, wnodes.size())) != RT_OK) return rc;
+        if (!wnodes.empty()) RT_HIP(hipMemcpy(ctx->dWNodes, wnodes.data(), wnodes.size() * sizeof(WideNode), hipMemcpyHostToDevice));
+        // Stack entries that do not fit in LDS: one column per lane of every wave the grid can hold.
+        const int deeper = std::max(0, ctx->wideStackNeed - kWideStack);
+        if ((uint32_t)deeper > ctx->pb.overflowDepth || ctx->pb.overflow == nullptr) {
+            const size_t waves = (size_t)ctx->numCUs * std::max(RT_WWIDE, RT_WWIDE_ALPHA) * (kBlock / 64);
+            if ((rc = devAlloc(ctx, &ctx->pb.overflow, waves * (size_t)std::max(deeper, 1) * 64)) != RT_OK) return rc;
+            ctx->pb.overflowDepth = (uint32_t)std::max(deeper, 1);
+        }
+    }
     if ((rc = devAlloc(ctx, &ctx->dNodes, nodes.size())) != RT_OK) return rc;
     if ((rc = devAlloc(ctx, &ctx->dTris, tris.size())) != RT_OK) return rc;
     if ((rc = devAlloc(ctx, &ctx->dModelDesc, descs.size())) != RT_OK) return rc;
@@ -1768,6 +2045,7 @@ int rt_commit_scene(rt_ctx *ctx, int objectCount, int modelsCount, int lightSour
     v.models = ctx->dStream[RT_SLOT_MODELS];
     v.textures = ctx->dStream[RT_SLOT_TEXTURES];
     v.nodes = ctx->dNodes;
+    v.wnodes = ctx->wideBvh ? ctx->dWNodes : nullptr;
     v.tris = ctx->dTris;
     v.modelDesc = ctx->dModelDesc;
     v.objectCount = objectCount;
@@ -2040,6 +2318,7 @@ int rt_get_stats(rt_ctx *ctx, rt_stats *out) {
     out->trace_ms = ctx->traceMs;
     out->total_ms = ctx->totalMs;
     out->trace_launches = ctx->traceLaunches;
+    out->max_stack = c[4];
     return RT_OK;
 }
 
@@ -2089,6 +2368,12 @@ int rt_set_option(rt_ctx *ctx, int option, int value) {
             if (value < 1) return RT_ERR_INVALID;
             ctx->maxPaths = (uint32_t)value;
             return RT_OK;
+        case RT_OPT_WIDE_BVH:
+            if (ctx->wideBvh == (value != 0)) return RT_OK;
+            ctx->wideBvh = value != 0;
+            if (!ctx->committed) return RT_OK;
+            ctx->dirty = true;   // the derived tree belongs to the committed scene: rebuild it now
+            return rt_commit_scene(ctx, ctx->objectCount, ctx->modelsCount, ctx->lightSourcesCount);
         default:
             return RT_ERR_INVALID;
     }
