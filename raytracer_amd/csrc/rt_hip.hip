@@ -138,6 +138,12 @@ struct PathBuffers {
 };
 
 __device__ __forceinline__ uint32_t laneId() { return threadIdx.x & 63u; }
+// The lane number from the execution-mask counters; volatile, so every use re-reads it.
+__device__ __forceinline__ uint32_t laneIdNow() {
+    uint32_t x;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(x));
+    return x;
+}
 
 // Appends `value` for every lane with `want`; one atomic per wave.  Must be
 // called by all lanes of the wave.
@@ -237,7 +243,7 @@ __device__ __forceinline__ float slabDistance(V3 bmin, V3 bmax, V3 ro, V3 inv, f
 // Byte k of a word as float (v_cvt_f32_ubyteK).
 template <int K> __device__ __forceinline__ float byteAsFloat(uint32_t w) { return (float)((w >> (8 * K)) & 0xffu); }
 
-// Entry distance of child K of a four-wide node, 1e20 when the ray misses it or enters it at or
+// Entry distance of child K of a four-wide node, 1e20 when the ray misses it or enters it
 // beyond `t`.  nx..fz are the words holding the planes the ray meets first / last on each axis,
 // (sx, bx) map a plane number q to the ray parameter q*sx + bx.
 typedef float float2v __attribute__((ext_vector_type(2)));
@@ -250,7 +256,7 @@ __device__ __forceinline__ float wideChildDistance(uint32_t nx, uint32_t ny, uin
     const float2v tz = __builtin_elementwise_fma((float2v){byteAsFloat<K>(nz), byteAsFloat<K>(fz)}, sz, bz);
     const float nearD = fmax3_(tx.x, ty.x, tz.x);
     const float farD = fmin3_(tx.y, ty.y, tz.y);
-    return (nearD < t && farD >= nearD && farD > 0.0f) ? nearD : 1e20f;
+    return (nearD <= t && farD >= nearD && farD > 0.0f) ? nearD : 1e20f;
 }
 
 // Orders two (distance, reference) pairs by distance.
@@ -283,6 +289,12 @@ __device__ __forceinline__ bool alphaCutRejects(const SceneView &sc, const Packe
 __device__ __forceinline__ void pinLoaded(const float4 &a, const float4 &b, const float4 &c) {
     asm volatile("" : : "v"(a.x), "v"(a.w), "v"(b.x), "v"(b.w), "v"(c.x), "v"(c.w));
 }
+
+// The same for whole 16-byte values: each must sit in four consecutive registers here, which keeps
+// the compiler from re-cutting the record into loads that straddle the 16-byte pieces.
+typedef float float4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void pinLoaded(float4v &a, float4v &b, float4v &c) { asm volatile("" : "+v"(a), "+v"(b), "+v"(c)); }
+__device__ __forceinline__ float4 asFloat4(const float4v &v) { return make_float4(v.x, v.y, v.z, v.w); }
 
 // Per-lane traversal state of the refilling variant.
 struct LaneRay {
@@ -417,9 +429,12 @@ __device__ __forceinline__ void intersectPrimitives(const SceneView &sc, LaneRay
 // incoherent rays run best around 32).  The traversal stack of each lane lives
 // in LDS ([entry][lane], conflict free).
 //
-// WIDE variants walk the four-wide tree instead: half as many dependent node loads per ray.  They
-// find the closest hit of every model like the others, but not by the reference's visiting order,
-// so the winner among hits at (nearly) the same distance can differ from the reference's.
+// WIDE variants walk the models' four-wide trees instead: half as many dependent node loads per
+// ray.  They find the same closest hit (the later model winning a tie between models, as in the
+// reference), but not by the reference's visiting order, so between two triangles of one model at
+// the same distance the other one may win.  (One tree over all models was tried: fewer nodes per
+// ray but slower, because lanes then mix the small models' leaves with the large model's inner
+// nodes and the two phases of the loop run emptier.)
 template <bool COUNT, int STACK, bool ALPHA, bool PRIMS, bool ROOTS, bool WIDE>
 __global__ __launch_bounds__(kBlock, WIDE ? (ALPHA ? RT_WWIDE_ALPHA : RT_WWIDE)
                                           : (STACK <= 20 ? (ALPHA ? RT_WALPHA : PRIMS ? 7 : RT_W20) : STACK <= 24 ? (ALPHA ? (RT_WALPHA < 6 ? RT_WALPHA : 6) : 6) : 5)) void k_trace(SceneView sc, PathBuffers pb, int extParity, int stage, int refillLanes, int innerShare) {
@@ -455,10 +470,83 @@ __global__ __launch_bounds__(kBlock, WIDE ? (ALPHA ? RT_WWIDE_ALPHA : RT_WWIDE)
     r.slot = 0;
     // Four-wide variants: this lane's column of the stack part that does not fit in LDS.
     int32_t *overflow = WIDE ? pb.overflow + (size_t)waveId * pb.overflowDepth * 64 + lane : nullptr;
+    // The four-wide variants run at the edge of their register budget: the lane's column of the LDS
+    // stack is addressed from the lane number re-read on the spot (two instructions) rather than from
+    // a value kept for the whole kernel, which the compiler would keep in scratch memory and reload
+    // at every push.
+    int32_t *const waveStack = &stackLds[0][0][0] + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * (STACK * 64);
+    auto stackSlot = [&](int32_t sp) -> int32_t * { return WIDE ? waveStack + sp * 64 + laneIdNow() : &stack[sp][lane]; };
     auto pushWide = [&](int32_t ref) {
-        if (r.sp < STACK) stack[r.sp][lane] = ref;
+        if (r.sp < STACK) *stackSlot(r.sp) = ref;
         else overflow[(size_t)(r.sp - STACK) * 64] = ref;
         r.sp++;
+    };
+    // Opens a four-wide node: the nearest child the ray enters becomes the lane's next reference,
+    // the others go on the stack with the farthest at the bottom.  True when no child is entered.
+    // Children are culled with maxT, the closest hit of this AND the earlier models (a triangle at
+    // exactly that distance still replaces it, so boxes entered at maxT stay in); the reference
+    // culls with the current model's hit only and walks every model's tree from the top.
+    auto openWideNode = [&](const float4 &n0, const float4 &n1, const float4 &n2, const float4 &n3) -> bool {
+        if (COUNT) cntNodes++;
+        const float sx1 = n1.x * r.inv.x, sy1 = n1.y * r.inv.y, sz1 = n1.z * r.inv.z;
+        const float bx1 = (n0.x - r.ro.x) * r.inv.x, by1 = (n0.y - r.ro.y) * r.inv.y, bz1 = (n0.z - r.ro.z) * r.inv.z;
+        const float2v sx = {sx1, sx1}, sy = {sy1, sy1}, sz = {sz1, sz1}, bx = {bx1, bx1}, by = {by1, by1}, bz = {bz1, bz1};
+        const uint32_t lox = __float_as_uint(n2.x), loy = __float_as_uint(n2.y), loz = __float_as_uint(n2.z);
+        const uint32_t hix = __float_as_uint(n3.x), hiy = __float_as_uint(n3.y), hiz = __float_as_uint(n3.z);
+        const bool ngx = r.inv.x < 0.0f, ngy = r.inv.y < 0.0f, ngz = r.inv.z < 0.0f;
+        const uint32_t nx = ngx ? hix : lox, fx = ngx ? lox : hix;
+        const uint32_t ny = ngy ? hiy : loy, fy = ngy ? loy : hiy;
+        const uint32_t nz = ngz ? hiz : loz, fz = ngz ? loz : hiz;
+        float d0 = wideChildDistance<0>(nx, ny, nz, fx, fy, fz, sx, sy, sz, bx, by, bz, r.maxT);
+        float d1 = wideChildDistance<1>(nx, ny, nz, fx, fy, fz, sx, sy, sz, bx, by, bz, r.maxT);
+        float d2 = wideChildDistance<2>(nx, ny, nz, fx, fy, fz, sx, sy, sz, bx, by, bz, r.maxT);
+        float d3 = wideChildDistance<3>(nx, ny, nz, fx, fy, fz, sx, sy, sz, bx, by, bz, r.maxT);
+        int32_t c0 = __float_as_int(n0.w), c1 = __float_as_int(n1.w), c2 = __float_as_int(n2.w), c3 = __float_as_int(n3.w);
+        orderPair(d0, c0, d1, c1);
+        orderPair(d2, c2, d3, c3);
+        orderPair(d0, c0, d2, c2);
+        orderPair(d1, c1, d3, c3);
+        orderPair(d1, c1, d2, c2);
+        if (!(d0 < 1e20f)) return true;
+        if (d3 < 1e20f) { pushWide(c3); }
+        if (d2 < 1e20f) { pushWide(c2); }
+        if (d1 < 1e20f) { pushWide(c1); }
+        r.ref = c0;
+        return false;
+    };
+    // Möller–Trumbore as hitTriangle writes it (src/RayScene.cpp:510-545); returns true when the
+    // hit waits for its alpha-cut lookup.
+    auto testTriangle = [&](uint32_t ti, const float4 &q0, const float4 &q1, const float4 &q2) -> bool {
+        if (COUNT) cntTris++;
+        const V3 A = v3(q0.x, q0.y, q0.z), ab = v3(q1.x, q1.y, q1.z), ac = v3(q2.x, q2.y, q2.z);
+        const V3 nrm = cross(ab, ac);
+        const float det = -dot(r.rd, nrm);
+        if (abs_(det) < 1e-8f) return false;
+        const V3 ao = r.ro - A;
+        const V3 dao = cross(ao, r.rd);
+        const float invDet = 1.0f / det;
+        const float t = dot(ao, nrm) * invDet;
+        if (t < 0.0f || t > r.maxT) return false;
+        // A later model's triangle at exactly the closest distance so far replaces the hit, a
+        // triangle of the same model does not (src/RayScene.cpp:535, :405-406).  The four-wide walk
+        // keeps one distance for both tests: maxT is this model's hit once mBest is set.
+        if (WIDE ? (r.mBest != kMiss && t == r.maxT) : (t >= r.tModel)) return false;
+        const float u = dot(ac, dao) * invDet;
+        const float v = -dot(ab, dao) * invDet;
+        if (u < 0.0f || v < 0.0f || u + v > 1.0f) return false;
+        if (ALPHA && (__float_as_int(q1.w) & kTriAlphaTest)) {
+            r.pendT = t;
+            r.pendU = u;
+            r.pendV = v;
+            r.pendTri = ti;
+            return true;
+        }
+        if (!WIDE) r.tModel = t;   // the four-wide walk keeps its closest hit in maxT alone
+        r.maxT = t;
+        r.mBest = ti;
+        r.mU = u;
+        r.mV = v;
+        return false;
     };
 
     for (;;) {
@@ -556,7 +644,7 @@ __global__ __launch_bounds__(kBlock, WIDE ? (ALPHA ? RT_WWIDE_ALPHA : RT_WWIDE)
             if (nPending > 0 && (nPending >= 8 || nPending == nActive)) {
                 if (pending) {
                     if (!alphaCutRejects(sc, sc.tris[r.pendTri], r.ro, r.rd, r.pendT)) {
-                        r.tModel = r.pendT;
+                        if (!WIDE) r.tModel = r.pendT;
                         r.maxT = r.pendT;
                         r.mBest = r.pendTri;
                         r.mU = r.pendU;
@@ -574,37 +662,9 @@ __global__ __launch_bounds__(kBlock, WIDE ? (ALPHA ? RT_WWIDE_ALPHA : RT_WWIDE)
         if (innerPhase) {
             if (WIDE) {
                 if (onInner) {
-                    if (COUNT) cntNodes++;
                     const float4 *np = reinterpret_cast<const float4 *>(&sc.wnodes[r.ref]);
                     const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
-                    const float sx1 = n1.x * r.inv.x, sy1 = n1.y * r.inv.y, sz1 = n1.z * r.inv.z;
-                    const float bx1 = (n0.x - r.ro.x) * r.inv.x, by1 = (n0.y - r.ro.y) * r.inv.y, bz1 = (n0.z - r.ro.z) * r.inv.z;
-                    const float2v sx = {sx1, sx1}, sy = {sy1, sy1}, sz = {sz1, sz1}, bx = {bx1, bx1}, by = {by1, by1}, bz = {bz1, bz1};
-                    const uint32_t lox = __float_as_uint(n2.x), loy = __float_as_uint(n2.y), loz = __float_as_uint(n2.z);
-                    const uint32_t hix = __float_as_uint(n3.x), hiy = __float_as_uint(n3.y), hiz = __float_as_uint(n3.z);
-                    const bool ngx = r.inv.x < 0.0f, ngy = r.inv.y < 0.0f, ngz = r.inv.z < 0.0f;
-                    const uint32_t nx = ngx ? hix : lox, fx = ngx ? lox : hix;
-                    const uint32_t ny = ngy ? hiy : loy, fy = ngy ? loy : hiy;
-                    const uint32_t nz = ngz ? hiz : loz, fz = ngz ? loz : hiz;
-                    float d0 = wideChildDistance<0>(nx, ny, nz, fx, fy, fz, sx, sy, sz, bx, by, bz, r.tModel);
-                    float d1 = wideChildDistance<1>(nx, ny, nz, fx, fy, fz, sx, sy, sz, bx, by, bz, r.tModel);
-                    float d2 = wideChildDistance<2>(nx, ny, nz, fx, fy, fz, sx, sy, sz, bx, by, bz, r.tModel);
-                    float d3 = wideChildDistance<3>(nx, ny, nz, fx, fy, fz, sx, sy, sz, bx, by, bz, r.tModel);
-                    int32_t c0 = __float_as_int(n0.w), c1 = __float_as_int(n1.w), c2 = __float_as_int(n2.w), c3 = __float_as_int(n3.w);
-                    orderPair(d0, c0, d1, c1);
-                    orderPair(d2, c2, d3, c3);
-                    orderPair(d0, c0, d2, c2);
-                    orderPair(d1, c1, d3, c3);
-                    orderPair(d1, c1, d2, c2);
-                    // Nearest child next, the others on the stack with the farthest at the bottom.
-                    if (d0 < 1e20f) {
-                        if (d3 < 1e20f) { pushWide(c3); }
-                        if (d2 < 1e20f) { pushWide(c2); }
-                        if (d1 < 1e20f) { pushWide(c1); }
-                        r.ref = c0;
-                    } else {
-                        pop = true;
-                    }
+                    pop = openWideNode(n0, n1, n2, n3);
                 }
             } else if (onInner) {
                 if (COUNT) cntNodes++;
@@ -633,53 +693,23 @@ __global__ __launch_bounds__(kBlock, WIDE ? (ALPHA ? RT_WWIDE_ALPHA : RT_WWIDE)
             const uint32_t code = ~(uint32_t)r.ref;
             const uint32_t first = code >> 2, ntri = code & 3u;
             bool parked = false;
-            // Möller–Trumbore as hitTriangle writes it (src/RayScene.cpp:510-545); returns true when the
-            // hit waits for its alpha-cut lookup.
-            auto testTriangle = [&](uint32_t ti, const float4 &q0, const float4 &q1, const float4 &q2) -> bool {
-                if (COUNT) cntTris++;
-                const V3 A = v3(q0.x, q0.y, q0.z), ab = v3(q1.x, q1.y, q1.z), ac = v3(q2.x, q2.y, q2.z);
-                const V3 nrm = cross(ab, ac);
-                const float det = -dot(r.rd, nrm);
-                if (abs_(det) < 1e-8f) return false;
-                const V3 ao = r.ro - A;
-                const V3 dao = cross(ao, r.rd);
-                const float invDet = 1.0f / det;
-                const float t = dot(ao, nrm) * invDet;
-                if (t < 0.0f || t > r.maxT || t >= r.tModel) return false;
-                const float u = dot(ac, dao) * invDet;
-                const float v = -dot(ab, dao) * invDet;
-                if (u < 0.0f || v < 0.0f || u + v > 1.0f) return false;
-                if (ALPHA && (__float_as_int(q1.w) & kTriAlphaTest)) {
-                    r.pendT = t;
-                    r.pendU = u;
-                    r.pendV = v;
-                    r.pendTri = ti;
-                    return true;
-                }
-                r.tModel = t;
-                r.maxT = t;
-                r.mBest = ti;
-                r.mU = u;
-                r.mV = v;
-                return false;
-            };
             if (WIDE && !ALPHA) {
                 // The usual leaf holds one or two triangles: fetch both in one round trip (the binary
                 // variants have no registers to spare for this: -10 % there, +2 % here).
-                const float4 *tp = reinterpret_cast<const float4 *>(&sc.tris[first]);
+                const float4v *tp = reinterpret_cast<const float4v *>(&sc.tris[first]);
                 if (ntri > 0u) {
                     const bool two = ntri > 1u;
-                    const float4 a0 = tp[0], a1 = tp[1], a2 = tp[2];
-                    float4 b0 = a0, b1 = a1, b2 = a2;
+                    float4v a0 = tp[0], a1 = tp[1], a2 = tp[2];
+                    float4v b0 = a0, b1 = a1, b2 = a2;
                     if (two) { b0 = tp[3]; b1 = tp[4]; b2 = tp[5]; }
                     pinLoaded(a0, a1, a2);
                     pinLoaded(b0, b1, b2);
-                    testTriangle(first, a0, a1, a2);
-                    if (two) testTriangle(first + 1u, b0, b1, b2);
+                    testTriangle(first, asFloat4(a0), asFloat4(a1), asFloat4(a2));
+                    if (two) testTriangle(first + 1u, asFloat4(b0), asFloat4(b1), asFloat4(b2));
                     for (uint32_t k = 2u; k < ntri; ++k) {
-                        const float4 q0 = tp[3 * k], q1 = tp[3 * k + 1], q2 = tp[3 * k + 2];
+                        float4v q0 = tp[3 * k], q1 = tp[3 * k + 1], q2 = tp[3 * k + 2];
                         pinLoaded(q0, q1, q2);
-                        testTriangle(first + k, q0, q1, q2);
+                        testTriangle(first + k, asFloat4(q0), asFloat4(q1), asFloat4(q2));
                     }
                 }
             } else {
@@ -697,24 +727,25 @@ __global__ __launch_bounds__(kBlock, WIDE ? (ALPHA ? RT_WWIDE_ALPHA : RT_WWIDE)
             if (!parked) {
                 if (ALPHA) r.resume = 0u;
                 pop = true;
-                occluded = r.tModel < r.tStop;
+                occluded = WIDE ? (r.mBest != kMiss && r.maxT < r.tStop) : (r.tModel < r.tStop);
             }
         }
         if (pop) {
             if (r.sp > 0 && !occluded) {
                 --r.sp;
                 if (WIDE && r.sp >= STACK) r.ref = overflow[(size_t)(r.sp - STACK) * 64];
-                else r.ref = stack[r.sp][lane];
+                else r.ref = *stackSlot(r.sp);
             } else {
                 if (r.mBest != kMiss) {
-                    r.closest = r.tModel;
+                    const float tHit = WIDE ? r.maxT : r.tModel;
+                    r.closest = tHit;
                     if (PRIMS) {
                         r.bestId = r.mBest;
                         r.bestU = r.mU;
                         r.bestV = r.mV;
                     } else {
                         HitRec rec;
-                        rec.t = r.tModel; rec.u = r.mU; rec.v = r.mV; rec.id = r.mBest;
+                        rec.t = tHit; rec.u = r.mU; rec.v = r.mV; rec.id = r.mBest;
                         *reinterpret_cast<float4 *>(&pb.hits[r.slot]) = *reinterpret_cast<const float4 *>(&rec);
                     }
                 }
@@ -1575,124 +1606,145 @@ int repackScene(rt_ctx *ctx, std::vector<PackedNode> &nodes, std::vector<PackedT
     return RT_OK;
 }
 
-// Four-wide tree of every model, collapsed from the binary tree of the model stream: a node
-// adopts the children of its child with the largest box until it has four (or only leaves are
-// left).  `descs` must have passed repackScene; rootRef is redirected to the new tree.
+// Four-wide tree of every model, collapsed from the binary tree of the model stream: a node adopts
+// the children of its child with the largest box until it has four (or only leaves are left).
+// `descs` must have passed repackScene; rootRef is redirected to the new tree.
 int buildWideNodes(rt_ctx *ctx, std::vector<ModelDesc> &descs, std::vector<WideNode> &wnodes) {
     const std::vector<float> &mdl = ctx->host[RT_SLOT_MODELS];
     ctx->wideStackNeed = 0;
-    struct Item { int node; int32_t wide; int held; };   // binary node to expand, its slot, entries its ancestors keep stacked
-    std::vector<Item> todo;
+
+    // All binary nodes in one array: box, children (indices into it), or the leaf reference.
+    struct Bin { float box[6]; int32_t left, right; int32_t leafRef; bool leaf; };
+    std::vector<Bin> bin;
+    std::vector<std::pair<int32_t, ModelDesc *>> roots;
+    double reach = 0.0;
     for (ModelDesc &d : descs) {
         if (d.nodesCount <= 0) continue;
-        auto word = [&](int n, int w) { return mdl[(size_t)d.nodeBase + (size_t)n * kNodeWords + w]; };
-        auto isLeaf = [&](int n) { return word(n, 8) != 0.0f; };
-        auto leafCount = [&](int n) { return f2i(word(n, 7)) - f2i(word(n, 6)); };
-        auto leafRef = [&](int n) { return ~(int32_t)((((uint32_t)(d.triBase + f2i(word(n, 6)))) << 2) | (uint32_t)leafCount(n)); };
-        auto area = [&](int n) {
-            const double ex = (double)word(n, 3) - word(n, 0), ey = (double)word(n, 4) - word(n, 1), ez = (double)word(n, 5) - word(n, 2);
-            return ex * ey + ey * ez + ez * ex;
-        };
-        if (isLeaf(0)) continue;   // rootRef already names the leaf
-        // Margin around every box for the rounding of the plane arithmetic on the device, whose
-        // operands are as large as the distance from the ray origin to the model: four units in the
-        // last place of the model's largest coordinate.
-        double reach = 0.0;
-        for (int w = 0; w < 6; ++w) reach = std::max(reach, (double)std::fabs(word(0, w)));
-        if (!(reach <= 1e15)) return RT_ERR_SCENE;
-        const double pad = std::ldexp(reach, -21);
-        d.rootRef = (int32_t)wnodes.size();
-        wnodes.emplace_back();
-        todo.push_back({0, d.rootRef, 0});
-        while (!todo.empty()) {
-            const Item it = todo.back();
-            todo.pop_back();
-            int kids[4] = {f2i(word(it.node, 6)), f2i(word(it.node, 7)), -1, -1};
-            int nk = 2;
-            while (nk < 4) {
-                int best = -1;
-                double bestArea = -1.0;
-                for (int i = 0; i < nk; ++i) {
-                    if (isLeaf(kids[i])) continue;
-                    const double a = area(kids[i]);
-                    if (best < 0 || a > bestArea) { best = i; bestArea = a; }
-                }
-                if (best < 0) break;
-                const int n = kids[best];
-                kids[best] = f2i(word(n, 6));
-                kids[nk++] = f2i(word(n, 7));
+        const int32_t base = (int32_t)bin.size();
+        bin.resize(bin.size() + (size_t)d.nodesCount);
+        for (int n = 0; n < d.nodesCount; ++n) {
+            const float *w = &mdl[(size_t)d.nodeBase + (size_t)n * kNodeWords];
+            Bin &b = bin[(size_t)base + n];
+            for (int k = 0; k < 6; ++k) b.box[k] = w[k];
+            b.leaf = w[8] != 0.0f;
+            if (b.leaf) {
+                const int first = f2i(w[6]), count = f2i(w[7]) - first;
+                b.left = b.right = -1;
+                b.leafRef = ~(int32_t)((((uint32_t)(d.triBase + first)) << 2) | (uint32_t)count);
+            } else {
+                b.left = base + f2i(w[6]);
+                b.right = base + f2i(w[7]);
+                b.leafRef = 0;
             }
-            // Leaves without triangles need no slot.
-            int kept = 0;
-            for (int i = 0; i < nk; ++i)
-                if (!(isLeaf(kids[i]) && leafCount(kids[i]) == 0)) kids[kept++] = kids[i];
-            nk = kept;
-            for (int i = 0; i < nk; ++i)
-                for (int w = 0; w < 6; ++w) {
-                    const float x = word(kids[i], w);
-                    if (!(std::fabs(x) <= 1e15f)) return RT_ERR_SCENE;   // also catches NaN
-                }
-
-            WideNode wn{};
-            uint32_t lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
-            for (int a = 0; a < 3; ++a) {
-                double lower = 0.0, upper = 0.0;
-                for (int i = 0; i < nk; ++i) {
-                    const double mn = word(kids[i], a), mx = word(kids[i], 3 + a);
-                    if (mn > mx) return RT_ERR_SCENE;
-                    if (i == 0 || mn < lower) lower = mn;
-                    if (i == 0 || mx > upper) upper = mx;
-                }
-                float o = (float)(lower - pad);
-                if ((double)o > lower - pad) o = std::nextafterf(o, -INFINITY);
-                const double extent = (upper + pad) - (double)o;
-                int e = -60;
-                if (extent > 0.0) e = std::max(-60, (int)std::ceil(std::log2(extent / 255.0)));
-                for (;; ++e) {
-                    const double step = std::ldexp(1.0, e);
-                    bool fits = true;
-                    uint32_t wlo = 0, whi = 0;
-                    for (int i = 0; i < 4 && fits; ++i) {
-                        uint32_t qlo = 255, qhi = 0;   // unused slot: inverted
-                        if (i < nk) {
-                            const double mn = (double)word(kids[i], a) - pad, mx = (double)word(kids[i], 3 + a) + pad;
-                            long ql = (long)std::floor((mn - (double)o) / step), qh = (long)std::ceil((mx - (double)o) / step);
-                            ql = std::max(0l, std::min(ql, 255l));
-                            while (ql > 0 && (double)o + (double)ql * step > mn) --ql;
-                            qh = std::max(qh, 0l);
-                            while (qh <= 255 && (double)o + (double)qh * step < mx) ++qh;
-                            if (qh > 255) { fits = false; break; }
-                            qlo = (uint32_t)ql;
-                            qhi = (uint32_t)qh;
-                        }
-                        wlo |= qlo << (8 * i);
-                        whi |= qhi << (8 * i);
-                    }
-                    if (fits) {
-                        wn.o[a] = o;
-                        wn.s[a] = (float)step;
-                        lo[a] = wlo;
-                        hi[a] = whi;
-                        break;
-                    }
-                }
-            }
-            for (int a = 0; a < 3; ++a) { wn.lo[a] = lo[a]; wn.hi[a] = hi[a]; }
-            int32_t refs[4] = {-1, -1, -1, -1};   // ~0: a leaf without triangles
-            const int held = it.held + std::max(nk - 1, 0);
-            ctx->wideStackNeed = std::max(ctx->wideStackNeed, held);
-            for (int i = 0; i < nk; ++i) {
-                if (isLeaf(kids[i])) {
-                    refs[i] = leafRef(kids[i]);
-                } else {
-                    refs[i] = (int32_t)wnodes.size();
-                    wnodes.emplace_back();
-                    todo.push_back({kids[i], refs[i], held});
-                }
-            }
-            wn.c0 = refs[0]; wn.c1 = refs[1]; wn.c2 = refs[2]; wn.c3 = refs[3];
-            wnodes[(size_t)it.wide] = wn;
         }
+        if (bin[(size_t)base].leaf) continue;   // rootRef already names the leaf
+        roots.push_back({base, &d});
+        for (int k = 0; k < 6; ++k) reach = std::max(reach, (double)std::fabs(bin[(size_t)base].box[k]));
+    }
+    if (roots.empty()) return RT_OK;
+    if (!(reach <= 1e15)) return RT_ERR_SCENE;   // also catches NaN
+    // Margin around every box for the rounding of the plane arithmetic on the device, whose operands
+    // are as large as the distance from the ray origin to the scene: four units in the last place of
+    // the scene's largest coordinate.
+    const double pad = std::ldexp(reach, -21);
+
+    auto leafCount = [&](int32_t n) { return (int)((~(uint32_t)bin[(size_t)n].leafRef) & 3u); };
+    auto area = [&](int32_t n) {
+        const float *b = bin[(size_t)n].box;
+        const double ex = (double)b[3] - b[0], ey = (double)b[4] - b[1], ez = (double)b[5] - b[2];
+        return ex * ey + ey * ez + ez * ex;
+    };
+    struct Item { int32_t node; int32_t wide; int held; };   // binary node to expand, its slot, entries its ancestors keep stacked
+    std::vector<Item> todo;
+    for (auto &rootOf : roots) {
+        rootOf.second->rootRef = (int32_t)wnodes.size();
+        wnodes.emplace_back();
+        todo.push_back({rootOf.first, rootOf.second->rootRef, 0});
+    }
+    while (!todo.empty()) {
+        const Item it = todo.back();
+        todo.pop_back();
+        int32_t kids[4] = {bin[(size_t)it.node].left, bin[(size_t)it.node].right, -1, -1};
+        int nk = 2;
+        while (nk < 4) {
+            int best = -1;
+            double bestArea = -1.0;
+            for (int i = 0; i < nk; ++i) {
+                if (bin[(size_t)kids[i]].leaf) continue;
+                const double a = area(kids[i]);
+                if (best < 0 || a > bestArea) { best = i; bestArea = a; }
+            }
+            if (best < 0) break;
+            const int32_t n = kids[best];
+            kids[best] = bin[(size_t)n].left;
+            kids[nk++] = bin[(size_t)n].right;
+        }
+        // Leaves without triangles need no slot.
+        int kept = 0;
+        for (int i = 0; i < nk; ++i)
+            if (!(bin[(size_t)kids[i]].leaf && leafCount(kids[i]) == 0)) kids[kept++] = kids[i];
+        nk = kept;
+        for (int i = 0; i < nk; ++i)
+            for (int w = 0; w < 6; ++w)
+                if (!(std::fabs(bin[(size_t)kids[i]].box[w]) <= 1e15f)) return RT_ERR_SCENE;
+
+        WideNode wn{};
+        for (int a = 0; a < 3; ++a) {
+            double lower = 0.0, upper = 0.0;
+            for (int i = 0; i < nk; ++i) {
+                const double mn = bin[(size_t)kids[i]].box[a], mx = bin[(size_t)kids[i]].box[3 + a];
+                if (mn > mx) return RT_ERR_SCENE;
+                if (i == 0 || mn < lower) lower = mn;
+                if (i == 0 || mx > upper) upper = mx;
+            }
+            float o = (float)(lower - pad);
+            if ((double)o > lower - pad) o = std::nextafterf(o, -INFINITY);
+            const double extent = (upper + pad) - (double)o;
+            int e = -60;
+            if (extent > 0.0) e = std::max(-60, (int)std::ceil(std::log2(extent / 255.0)));
+            for (;; ++e) {
+                const double step = std::ldexp(1.0, e);
+                bool fits = true;
+                uint32_t wlo = 0, whi = 0;
+                for (int i = 0; i < 4 && fits; ++i) {
+                    uint32_t qlo = 255, qhi = 0;   // unused slot: inverted
+                    if (i < nk) {
+                        const double mn = (double)bin[(size_t)kids[i]].box[a] - pad, mx = (double)bin[(size_t)kids[i]].box[3 + a] + pad;
+                        long ql = (long)std::floor((mn - (double)o) / step), qh = (long)std::ceil((mx - (double)o) / step);
+                        ql = std::max(0l, std::min(ql, 255l));
+                        while (ql > 0 && (double)o + (double)ql * step > mn) --ql;
+                        qh = std::max(qh, 0l);
+                        while (qh <= 255 && (double)o + (double)qh * step < mx) ++qh;
+                        if (qh > 255) { fits = false; break; }
+                        qlo = (uint32_t)ql;
+                        qhi = (uint32_t)qh;
+                    }
+                    wlo |= qlo << (8 * i);
+                    whi |= qhi << (8 * i);
+                }
+                if (fits) {
+                    wn.o[a] = o;
+                    wn.s[a] = (float)step;
+                    wn.lo[a] = wlo;
+                    wn.hi[a] = whi;
+                    break;
+                }
+            }
+        }
+        int32_t refs[4] = {-1, -1, -1, -1};   // ~0: a leaf without triangles
+        const int held = it.held + std::max(nk - 1, 0);
+        ctx->wideStackNeed = std::max(ctx->wideStackNeed, held);
+        for (int i = 0; i < nk; ++i) {
+            if (bin[(size_t)kids[i]].leaf) {
+                refs[i] = bin[(size_t)kids[i]].leafRef;
+            } else {
+                refs[i] = (int32_t)wnodes.size();
+                wnodes.emplace_back();
+                todo.push_back({kids[i], refs[i], held});
+            }
+        }
+        wn.c0 = refs[0]; wn.c1 = refs[1]; wn.c2 = refs[2]; wn.c3 = refs[3];
+        wnodes[(size_t)it.wide] = wn;
     }
     return RT_OK;
 }
