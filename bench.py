@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend; gloo + --one-device rehearses the N>1 path on a single GPU")
     ap.add_argument("--one-device", action="store_true", help="rehearsal only: every rank uses GPU 0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-optin", action="store_true", help="skip the informational opt-in four-wide-tree figure")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
     return ap.parse_args()
 
@@ -209,6 +210,23 @@ def main():
             },
             "host_scene_build_s": round(t_build, 2),
         }
+        if world == 1 and not wide and not args.no_optin:
+            # Informational second figure, outside the timed region above: the same workload on the
+            # opt-in four-wide trees (RT_OPT_WIDE_BVH), which find the same closest hits but may pick
+            # the other triangle of an exact distance tie.  `value` stays the reference-order figure.
+            be.set_option(capi.RT_OPT_WIDE_BVH, 1)
+            step(0)
+            be.reset_stats()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for k in range(2):
+                step(1 + k)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t1
+            wst = be.stats()
+            out["optin_wide_tree"] = {"value": round(wst["rays"] / dt / 1e6, 3), "unit": "Mrays/s", "steps": 2, "ms_per_step": round(dt / 2 * 1e3, 3),
+                                      "trace_only_mrays_per_s": round(wst["rays"] / max(wst["trace_ms"] / 1e3, 1e-12) / 1e6, 2)}
+            be.set_option(capi.RT_OPT_WIDE_BVH, 0)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, scene, cam, rtype)
         print(json.dumps(out), flush=True)

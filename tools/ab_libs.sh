@@ -4,6 +4,6 @@ cd raytracer_amd/lib && cp librt_hip.so base.so && cd ../..
 for v in "$@"; do
   cp raytracer_amd/lib/$v.so raytracer_amd/lib/librt_hip.so
   echo -n "$v: "
-  timeout -k 10 200 python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline $AB_ARGS 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.readline()); r=d['roofline']; print(d['value'], 'ms/step', d['ms_per_step'], 'trace-only', r['trace_only_mrays_per_s'], 'trace share', r['trace_fraction_of_step'])"
+  timeout -k 10 200 python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-optin $AB_ARGS 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.readline()); r=d['roofline']; print(d['value'], 'ms/step', d['ms_per_step'], 'trace-only', r['trace_only_mrays_per_s'], 'trace share', r['trace_fraction_of_step'])"
 done
 cp raytracer_amd/lib/base.so raytracer_amd/lib/librt_hip.so

@@ -3,8 +3,8 @@ set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 export $2
 rm -rf gpurun_out/pmc_$1_tc gpurun_out/pmc_$1_fetch
-timeout -s KILL 300 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum --output-format csv -d gpurun_out/pmc_$1_tc -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/pmc_$1_tc.log 2>&1
-timeout -s KILL 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_$1_fetch -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/pmc_$1_fetch.log 2>&1
+timeout -s KILL 300 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum --output-format csv -d gpurun_out/pmc_$1_tc -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-optin > gpurun_out/pmc_$1_tc.log 2>&1
+timeout -s KILL 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_$1_fetch -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-optin > gpurun_out/pmc_$1_fetch.log 2>&1
 python3 - <<PY
 import csv, glob, collections
 for kind in ("tc", "fetch"):

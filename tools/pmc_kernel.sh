@@ -2,7 +2,7 @@
 set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/pmc_$1_sq
-timeout -s KILL 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES --output-format csv -d gpurun_out/pmc_$1_sq -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/pmc_$1_sq.log 2>&1
+timeout -s KILL 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES --output-format csv -d gpurun_out/pmc_$1_sq -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-optin > gpurun_out/pmc_$1_sq.log 2>&1
 python3 - <<PY
 import csv, glob, collections
 f = glob.glob("gpurun_out/pmc_$1_sq/*/*_counter_collection.csv")[0]
