@@ -389,9 +389,11 @@ def test_sah_tree_mode_matches_checker(backend, rtype):
     assert np.array_equal(got, want, equal_nan=True)
 
 
-def test_cpp_example_program_renders_the_same_picture(tmp_path):
+@pytest.mark.parametrize("flags", [[], ["--wide"]])
+def test_cpp_example_program_renders_the_same_picture(tmp_path, flags):
     """examples/rt_render drives the C++ host API the way the reference's main() does; its PNG must
-    equal the display pass of the same scene rendered through the C ABI from here."""
+    equal the display pass of the same scene rendered through the C ABI from here (also when the
+    program switches the backend to its four-wide trees: no distance ties in this scene)."""
     import os
     import subprocess
     from PIL import Image
@@ -401,7 +403,7 @@ def test_cpp_example_program_renders_the_same_picture(tmp_path):
     assert os.path.exists(exe), "build it with `make`"
     glb = room_glb(tmp_path / "room.glb", nu=24, nv=8)
     out = tmp_path / "cpp.png"
-    run = subprocess.run([exe, "--rgb", "--frames", "3", "--size", "64x48", "--bounces", "4", "--out", str(out), glb],
+    run = subprocess.run([exe, "--rgb", *flags, "--frames", "3", "--size", "64x48", "--bounces", "4", "--out", str(out), glb],
                          capture_output=True, text=True, timeout=120)
     assert run.returncode == 0, run.stderr
     b = capi.Backend(0)

@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--ray-per-pixel", type=int, default=1)
     ap.add_argument("--bounces", type=int, default=4)
     ap.add_argument("--spectral", action="store_true")
+    ap.add_argument("--wide", action="store_true", help="walk the opt-in four-wide trees (RT_OPT_WIDE_BVH)")
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--out", default="render.png")
     ap.add_argument("--pfm")
@@ -39,6 +40,8 @@ def main():
     scene = capi.Scene(a.scene, nu=a.nu, nv=a.nv)
     cam = capi.make_camera(width=a.width, height=a.height, bounces=a.bounces, ray_per_pixel=a.ray_per_pixel)
     be = capi.Backend(a.device)
+    if a.wide:
+        be.set_option(capi.RT_OPT_WIDE_BVH, 1)
     be.upload_scene(scene)
     be.resize(a.width, a.height)
     be.set_frame(cam, scene.sky, capi.RT_TYPE_SPECTRAL if a.spectral else capi.RT_TYPE_RGB)
