@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--wide", action="store_true", help="opt-in four-wide tree (RT_OPT_WIDE_BVH): closest hits, not the reference's visiting order")
     ap.add_argument("--scene", default="cornell_knot")
     ap.add_argument("--spectral", action="store_true")
+    ap.add_argument("--hero", action="store_true", help="Spectral with four wavelengths per camera sample (the reference's HERO_WAVELENGTH_ENABLE 1)")
     ap.add_argument("--shard", choices=["sample", "tile"], default="sample",
                     help="N>1: sample-split (frames dealt round-robin) or tile-split (8x8 tiles dealt round-robin)")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend; gloo + --one-device rehearses the N>1 path on a single GPU")
@@ -75,6 +76,7 @@ def main():
         else:
             dist.init_process_group(args.dist_backend)
 
+    args.spectral = args.spectral or args.hero
     rtype = capi.RT_TYPE_SPECTRAL if args.spectral else capi.RT_TYPE_RGB
     t_build = time.time()
     scene = capi.Scene(args.scene, nu=args.nu, nv=args.nv, tex_size=args.tex_size, bvh=args.bvh)
@@ -84,6 +86,8 @@ def main():
     be = capi.Backend(local_rank)
     if args.wide:
         be.set_option(capi.RT_OPT_WIDE_BVH, 1)
+    if args.hero:
+        be.set_option(capi.RT_OPT_HERO_WAVELENGTH, 1)
     wide = args.wide or os.environ.get("RT_WIDE_BVH", "0") not in ("", "0")
     be.upload_scene(scene)
     be.resize(args.width, args.height)
@@ -182,7 +186,7 @@ def main():
             "config": {
                 "workload": f"{args.scene} ({'procedural dragon-class mesh, ' if 'knot' in args.scene else ''}{triangles} triangles in {scene.models_count} models), "
                             f"{args.width}x{args.height}, {args.spp} spp per {'image' if tile_split else 'GPU'} per step, primary+{args.bounces} bounces, "
-                            f"{'Spectral' if args.spectral else 'RGB'} NEE+MIS" + (", opt-in SAH trees (not the reference's traversal order)" if args.bvh == "sah" else "")
+                            f"{'Spectral' if args.spectral else 'RGB'} NEE+MIS" + (", hero-wavelength mode (4 wavelengths per camera sample)" if args.hero else "") + (", opt-in SAH trees (not the reference's traversal order)" if args.bvh == "sah" else "")
                             + (", opt-in four-wide tree (closest hits, not the reference's traversal order)" if wide else ""),
                 "sharding": (("tile-split 8x8 tiles" if tile_split else "sample-split frames") + f", scene replicated, {'RCCL' if args.dist_backend == 'nccl' else args.dist_backend} sum-reduce of the fp32 accumulation buffer") if distributed else "single GPU",
                 "rays_per_camera_sample": round(total_rays / max(total_samples, 1), 4),
@@ -261,11 +265,11 @@ def cpu_baseline(args, scene, cam, rtype):
     W, H = args.width, args.height
     # Calibrate on one full 1-spp frame, then size the sample (whole frames) for ~cpu-seconds of work.
     t0 = time.perf_counter()
-    _, st = orc.render(cam, rtype, 1, 1, 1, threads=threads)
+    _, st = orc.render(cam, rtype, 1, 1, 1, threads=threads, hero_wavelength=args.hero)
     dt = time.perf_counter() - t0
     frames = int(max(1, min(64, round(args.cpu_seconds / max(dt, 1e-3)))))
     t0 = time.perf_counter()
-    _, st = orc.render(cam, rtype, 1, frames, 1, threads=threads)
+    _, st = orc.render(cam, rtype, 1, frames, 1, threads=threads, hero_wavelength=args.hero)
     dt = time.perf_counter() - t0
     rate = st["rays"] / max(dt, 1e-9)
     y0, want_rows = 0, H

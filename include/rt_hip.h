@@ -154,8 +154,8 @@ int rt_reset_stats(rt_ctx *ctx);
 /* Enables per-ray node/triangle visit counting (slower; off by default). */
 int rt_set_counters(rt_ctx *ctx, int enabled);
 
-/* Switches (no reference counterpart).  Only RT_OPT_SPECTRAL_PDF_AS_WRITTEN and RT_OPT_WIDE_BVH
- * can change output values.
+/* Switches.  Only RT_OPT_SPECTRAL_PDF_AS_WRITTEN, RT_OPT_HERO_WAVELENGTH and RT_OPT_WIDE_BVH can
+ * change output values; only RT_OPT_HERO_WAVELENGTH has a counterpart in the reference.
  *   RT_OPT_SHADOW_EARLY_OUT  RGB shadow rays stop at the first hit nearer than
  *                            distToLight - 1e-4: such a hit already fails the reference's
  *                            visibility test (src/RayTracer.cpp:439), so finishing the
@@ -183,9 +183,15 @@ int rt_set_counters(rt_ctx *ctx, int enabled);
  *                            in the order of hitModel (src/RayScene.cpp:681-736), so where two
  *                            triangles are hit at the same distance (shared edges, coplanar
  *                            duplicates) the other one may win.  Default 0: the reference's order,
- *                            bit-identical hits.  Rebuilds the derived tree of a committed scene. */
+ *                            bit-identical hits.  Rebuilds the derived tree of a committed scene.
+ *   RT_OPT_HERO_WAVELENGTH   1: the Spectral integrator built with HERO_WAVELENGTH_ENABLE 1
+ *                            (src/RayTracer.cpp:607, 1257-1280, 1357-1364): every camera sample traces
+ *                            four wavelengths, spread over the range from one random offset, along
+ *                            the same camera ray and each from the same seed (it is passed by value,
+ *                            src/RayTracer.cpp:1051), and adds the mean of their XYZ contributions.  Four times the rays per
+ *                            sample.  Default 0, the reference's default.  Ignored by RT_TYPE_RGB. */
 enum { RT_OPT_SHADOW_EARLY_OUT = 1, RT_OPT_REFILL_LANES = 2, RT_OPT_INNER_SHARE = 3, RT_OPT_MAX_PATHS = 4, RT_OPT_TILE_MAJOR = 5,
-       RT_OPT_SPECTRAL_PDF_AS_WRITTEN = 6, RT_OPT_WIDE_BVH = 7 };
+       RT_OPT_SPECTRAL_PDF_AS_WRITTEN = 6, RT_OPT_WIDE_BVH = 7, RT_OPT_HERO_WAVELENGTH = 8 };
 int rt_set_option(rt_ctx *ctx, int option, int value);
 
 const char *rt_strerror(int status);

@@ -89,6 +89,7 @@ struct Ctx {
     // Spectral integrator only: leave the light-selection probability out of the area pdf, as the
     // Spectral shader text has it (type bit 8 of orc_render); default is the RGB convention.
     bool spectralPdfAsWritten = false;
+    bool heroWavelength = false;   // HERO_WAVELENGTH_ENABLE 1 (src/RayTracer.cpp:607, 1357-1364)
 };
 
 // ---- GLSL structs (src/RayTracer.cpp:43-88, src/RayScene.cpp:215-257) -------------
@@ -935,6 +936,14 @@ static V3 framePixel(Ctx &c, int px, int py, int type) {
             c.cnt.cameraSamples++;
             if (type == 0) {
                 color = color + traceColor(c, r, seed);
+            } else if (c.heroWavelength) {
+                // src/RayTracer.cpp:1358-1364: four wavelengths per camera sample along the same camera
+                // ray; the seed goes in by value (:1051), so all four start from the same state.
+                float base_offset = (rtm::rand_float(seed) + (float)(i * ssq) + (float)j) * wl_dt;
+                float lambdas[4], radiances[4];
+                get_hero_wavelengths(base_offset, lambdas);
+                for (int k = 0; k < 4; ++k) radiances[k] = traceColorWavelength(c, r, lambdas[k], seed);
+                color = color + hero_wavelengths_to_rgb(lambdas, radiances, wl_pdf);
             } else {
                 float lambda = (rtm::rand_float(seed) + (float)(i * ssq) + (float)j) * wl_dt + WL_MIN;
                 float radiance = traceColorWavelength(c, r, lambda, seed);
@@ -1048,6 +1057,7 @@ int orc_render(const orc_scene *s, const Camera *cam, const float sky[3], int ty
     parallelRows(y0, y1, threads, [&](int y, int tid) {
         Ctx c{&s->sc, *cam, v3(sky[0], sky[1], sky[2]), 0u, Counters()};
         c.spectralPdfAsWritten = (typeAndFlags & 0x100) != 0;
+        c.heroWavelength = (typeAndFlags & 0x200) != 0;
         for (int x = x0; x < x1; ++x) {
             size_t at = ((size_t)y * W + x) * 4;
             for (uint32_t k = 0; k < n_frames; ++k) {

@@ -82,6 +82,7 @@ struct FrameParams {
     uint32_t S;         // samples per frame = ssq*ssq
     int32_t shadowEarlyOut;   // RGB shadow rays stop at the first hit that already proves occlusion
     int32_t spectralPdfAsWritten;   // Spectral: area pdf without the light-selection probability
+    int32_t hero;             // Spectral: four wavelengths per camera sample (HERO_WAVELENGTH_ENABLE, src/RayTracer.cpp:607)
     // Tile-split sharding: this context renders only the 8x8 tiles whose row-major
     // index i satisfies i % tileStride == tileOffset (all tiles when stride is 1).
     uint32_t tileOffset, tileStride;
@@ -174,8 +175,21 @@ __device__ __forceinline__ uint32_t pathIndex(const FrameParams &fp, const Batch
 // ---- k_generate -----------------------------------------------------------------------
 // Camera ray of fragment main() (src/RayTracer.cpp:559-578 / 1333-1366): jitter
 // in units of (1/W)*right and (1/H)*up, first draw horizontal.
+//
+// Hero-wavelength mode (src/RayTracer.cpp:1357-1364) traces four wavelengths per camera sample one
+// after the other along the same camera ray, each from the same seed: the batch runs the bounce
+// loop four times, and this kernel starts pass `heroPass` (0..3; -1 = mode off).  Passes after the
+// first fold the finished wavelength into the sample's XYZ sum (kept in neeC, which the Spectral
+// integrator does not otherwise use) and restart the path.
+// get_hero_wavelengths, src/RayTracer.cpp:1259-1272, one component; mod(x, y) = x - y*floor(x/y).
+__device__ __forceinline__ float heroWavelength(int k, float baseOffset) {
+    const float stride = kWlRange / 4.0f;
+    const float x = (kWlMin + stride * ((float)k + baseOffset)) - kWlMin;
+    return (x - kWlRange * floor_(x / kWlRange)) + kWlMin;
+}
+
 template <bool SPECTRAL>
-__global__ __launch_bounds__(kBlock) void k_generate(FrameParams fp, Batch bt, PathBuffers pb) {
+__global__ __launch_bounds__(kBlock) void k_generate(FrameParams fp, Batch bt, PathBuffers pb, int heroPass) {
     const uint32_t total = bt.K * fp.npt;
     const uint32_t stride = gridDim.x * kBlock;
     for (uint32_t base = blockIdx.x * kBlock + (threadIdx.x & ~63u); base < total; base += stride) {
@@ -212,7 +226,20 @@ __global__ __launch_bounds__(kBlock) void k_generate(FrameParams fp, Batch bt, P
                 r.ox = fp.position.x; r.oy = fp.position.y; r.oz = fp.position.z; r.pad0 = 0.0f;
                 r.dx = d.x; r.dy = d.y; r.dz = d.z; r.pad1 = kNeverStop;
                 pb.rays[p] = r;
-                if (SPECTRAL) {
+                if (SPECTRAL && heroPass >= 0) {
+                    // The seed is passed to traceColorWavelength by value (src/RayTracer.cpp:1051), so
+                    // every wavelength of the sample starts from the same state: the one after this draw.
+                    const float baseOffset = (rand_float(seed) + (float)(i * fp.ssq) + (float)j) * fp.wlDt;
+                    float4 sum = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    if (heroPass > 0) {
+                        sum = pb.neeC[p];
+                        const V3 xyz = v3(sum.x, sum.y, sum.z) + cieXYZ(pb.stA[p].z) * (pb.stB[p].x / fp.wlPdf);
+                        sum = make_float4(xyz.x, xyz.y, xyz.z, 0.0f);
+                    }
+                    pb.neeC[p] = sum;
+                    pb.stA[p] = make_float4(1.0f, 1.0f, heroWavelength(heroPass, baseOffset), 0.0f);
+                    pb.stB[p] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(seed));
+                } else if (SPECTRAL) {
                     float lambda = (rand_float(seed) + (float)(i * fp.ssq) + (float)j) * fp.wlDt + kWlMin;
                     pb.stA[p] = make_float4(1.0f, 1.0f, lambda, 0.0f);
                     pb.stB[p] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(seed));
@@ -1266,7 +1293,12 @@ __global__ __launch_bounds__(kBlock) void k_resolve(FrameParams fp, Batch bt, Pa
             const float4 sB = pb.stB[path];
             if (SPECTRAL) {
                 const float lambda = pb.stA[path].z;
-                c = c + cieXYZ(lambda) * (sB.x / fp.wlPdf);
+                if (fp.hero) {   // hero_wavelengths_to_rgb, src/RayTracer.cpp:1274-1280: the fourth term and the mean
+                    const float4 sum = pb.neeC[path];
+                    c = c + (v3(sum.x, sum.y, sum.z) + cieXYZ(lambda) * (sB.x / fp.wlPdf)) / 4.0f;
+                } else {
+                    c = c + cieXYZ(lambda) * (sB.x / fp.wlPdf);
+                }
             } else {
                 c = c + v3(sB.x, sB.y, sB.z);
             }
@@ -1356,6 +1388,7 @@ struct rt_ctx {
     bool hasAlphaTest = false;
     bool shadowEarlyOut = true;
     bool spectralPdfAsWritten = false;
+    bool heroWavelength = false;
     uint32_t tileOffset = 0, tileStride = 1;
     bool planesInner = true;   // tile-major path order inside a batch
     int refillLanes = 32;   // idle lanes that trigger a refill for stages > 0
@@ -1844,26 +1877,29 @@ int runBatch(rt_ctx *ctx, const Batch &bt) {
     const FrameParams &fp = ctx->fp;
     const bool spectral = ctx->type == RT_TYPE_SPECTRAL;
     const int cnt = ctx->countersOn ? 1 : 0;
-    RT_HIP(hipMemsetAsync(ctx->pb.stages, 0, sizeof(Stage) * ((size_t)fp.bounces + 2), ctx->stream));
-
     const uint64_t paths = (uint64_t)bt.K * fp.npt;
     const int gGen = gridFor(ctx, paths, 16), gShade = gridFor(ctx, paths, 8);
-    if (spectral) hipLaunchKernelGGL(k_generate<true>, dim3(gGen), dim3(kBlock), 0, ctx->stream, fp, bt, ctx->pb);
-    else hipLaunchKernelGGL(k_generate<false>, dim3(gGen), dim3(kBlock), 0, ctx->stream, fp, bt, ctx->pb);
+    // Hero-wavelength mode runs the whole bounce loop once per wavelength of the camera sample.
+    const int passes = (spectral && fp.hero) ? 4 : 1;
+    for (int pass = 0; pass < passes; ++pass) {
+        RT_HIP(hipMemsetAsync(ctx->pb.stages, 0, sizeof(Stage) * ((size_t)fp.bounces + 2), ctx->stream));
+        if (spectral) hipLaunchKernelGGL(k_generate<true>, dim3(gGen), dim3(kBlock), 0, ctx->stream, fp, bt, ctx->pb, fp.hero ? pass : -1);
+        else hipLaunchKernelGGL(k_generate<false>, dim3(gGen), dim3(kBlock), 0, ctx->stream, fp, bt, ctx->pb, -1);
 
-    for (int b = 0; b <= fp.bounces; ++b) {
-        launchTrace(ctx, b & 1, b);
-        if (b > 0) {
-            if (spectral) hipLaunchKernelGGL(k_connect<true>, dim3(gShade), dim3(kBlock), 0, ctx->stream, ctx->view, bt, ctx->pb, b, cnt, fp.shadowEarlyOut);
-            else hipLaunchKernelGGL(k_connect<false>, dim3(gShade), dim3(kBlock), 0, ctx->stream, ctx->view, bt, ctx->pb, b, cnt, fp.shadowEarlyOut);
+        for (int b = 0; b <= fp.bounces; ++b) {
+            launchTrace(ctx, b & 1, b);
+            if (b > 0) {
+                if (spectral) hipLaunchKernelGGL(k_connect<true>, dim3(gShade), dim3(kBlock), 0, ctx->stream, ctx->view, bt, ctx->pb, b, cnt, fp.shadowEarlyOut);
+                else hipLaunchKernelGGL(k_connect<false>, dim3(gShade), dim3(kBlock), 0, ctx->stream, ctx->view, bt, ctx->pb, b, cnt, fp.shadowEarlyOut);
+            }
+            if (spectral) hipLaunchKernelGGL(k_shade_spectral, dim3(gShade), dim3(kBlock), 0, ctx->stream, ctx->view, fp, bt, ctx->pb, b, cnt);
+            else hipLaunchKernelGGL(k_shade_rgb, dim3(gShade), dim3(kBlock), 0, ctx->stream, ctx->view, fp, bt, ctx->pb, b, cnt);
         }
-        if (spectral) hipLaunchKernelGGL(k_shade_spectral, dim3(gShade), dim3(kBlock), 0, ctx->stream, ctx->view, fp, bt, ctx->pb, b, cnt);
-        else hipLaunchKernelGGL(k_shade_rgb, dim3(gShade), dim3(kBlock), 0, ctx->stream, ctx->view, fp, bt, ctx->pb, b, cnt);
+        const int last = fp.bounces + 1;
+        launchTrace(ctx, -1, last);
+        if (spectral) hipLaunchKernelGGL(k_connect<true>, dim3(gShade), dim3(kBlock), 0, ctx->stream, ctx->view, bt, ctx->pb, last, cnt, fp.shadowEarlyOut);
+        else hipLaunchKernelGGL(k_connect<false>, dim3(gShade), dim3(kBlock), 0, ctx->stream, ctx->view, bt, ctx->pb, last, cnt, fp.shadowEarlyOut);
     }
-    const int last = fp.bounces + 1;
-    launchTrace(ctx, -1, last);
-    if (spectral) hipLaunchKernelGGL(k_connect<true>, dim3(gShade), dim3(kBlock), 0, ctx->stream, ctx->view, bt, ctx->pb, last, cnt, fp.shadowEarlyOut);
-    else hipLaunchKernelGGL(k_connect<false>, dim3(gShade), dim3(kBlock), 0, ctx->stream, ctx->view, bt, ctx->pb, last, cnt, fp.shadowEarlyOut);
 
     const int gRes = gridFor(ctx, fp.npt, 16);
     if (spectral) hipLaunchKernelGGL(k_resolve<true>, dim3(gRes), dim3(kBlock), 0, ctx->stream, fp, bt, ctx->pb, ctx->dAccum, ctx->dPartial);
@@ -2171,6 +2207,7 @@ int rt_set_frame(rt_ctx *ctx, const rt_camera *cam, const float sky_linear[3], i
     fp.S = (uint32_t)fp.ssq * (uint32_t)fp.ssq;
     fp.shadowEarlyOut = (ctx->shadowEarlyOut && type == RT_TYPE_RGB) ? 1 : 0;
     fp.spectralPdfAsWritten = ctx->spectralPdfAsWritten ? 1 : 0;
+    fp.hero = (ctx->heroWavelength && type == RT_TYPE_SPECTRAL) ? 1 : 0;
     fp.tileOffset = ctx->tileOffset;
     fp.tileStride = ctx->tileStride;
     ctx->type = type;
@@ -2321,8 +2358,8 @@ int rt_trace_primary(rt_ctx *ctx, uint32_t frame, int32_t *model, int32_t *ident
     bt.planesInner = 0u;   // one plane: both orders coincide
     RT_HIP(hipMemsetAsync(ctx->pb.stages, 0, sizeof(Stage) * 2, ctx->stream));
     const int gGen = gridFor(ctx, fp.npt, 16);
-    if (ctx->type == RT_TYPE_SPECTRAL) hipLaunchKernelGGL(k_generate<true>, dim3(gGen), dim3(kBlock), 0, ctx->stream, fp, bt, ctx->pb);
-    else hipLaunchKernelGGL(k_generate<false>, dim3(gGen), dim3(kBlock), 0, ctx->stream, fp, bt, ctx->pb);
+    if (ctx->type == RT_TYPE_SPECTRAL) hipLaunchKernelGGL(k_generate<true>, dim3(gGen), dim3(kBlock), 0, ctx->stream, fp, bt, ctx->pb, -1);
+    else hipLaunchKernelGGL(k_generate<false>, dim3(gGen), dim3(kBlock), 0, ctx->stream, fp, bt, ctx->pb, -1);
     launchTrace(ctx, 0, 0);
     RT_HIP(hipGetLastError());
     std::vector<HitRec> hits(fp.npt);
@@ -2412,6 +2449,10 @@ int rt_set_option(rt_ctx *ctx, int option, int value) {
         case RT_OPT_SPECTRAL_PDF_AS_WRITTEN:
             ctx->spectralPdfAsWritten = value != 0;
             ctx->fp.spectralPdfAsWritten = value != 0 ? 1 : 0;
+            return RT_OK;
+        case RT_OPT_HERO_WAVELENGTH:
+            ctx->heroWavelength = value != 0;
+            ctx->fp.hero = (ctx->heroWavelength && ctx->type == RT_TYPE_SPECTRAL) ? 1 : 0;
             return RT_OK;
         case RT_OPT_TILE_MAJOR:
             ctx->planesInner = value != 0;

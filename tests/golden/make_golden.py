@@ -22,7 +22,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 from raytracer_amd import capi  # noqa: E402
 from oracle_binding import OracleScene  # noqa: E402
 
-from golden_cases import CASES, scene_name  # noqa: E402
+from golden_cases import CASES, HERO_CASES, scene_name  # noqa: E402
 
 
 def stream_digest(scene):
@@ -57,6 +57,15 @@ def main():
             spectral_rays=np.array(st2["rays"], np.int64),
         )
         print(case, "written:", stream_digest(scene)[:12], st)
+    for case, (name, kw, W, H, bounces, rpp, frames) in HERO_CASES.items():
+        path = os.path.join(HERE, f"hero_{case}.npz")
+        if (only and f"hero_{case}" not in only) or (not only and os.path.exists(path)):
+            continue
+        scene = capi.Scene(name, **kw)
+        cam = capi.make_camera(width=W, height=H, bounces=bounces, ray_per_pixel=rpp)
+        spec, st = OracleScene(scene).render(cam, 1, 1, frames, 1, hero_wavelength=True)
+        np.savez_compressed(path, spectral=spec, spectral_rays=np.array(st["rays"], np.int64))
+        print("hero", case, "written:", st)
 
 
 if __name__ == "__main__":

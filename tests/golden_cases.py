@@ -17,6 +17,13 @@ CASES = {
     "glb_room": ("glb:{golden}/room.glb", {}, 48, 36, 4, 4, 2),
 }
 
+# Spectral integrator in hero-wavelength mode (the reference's HERO_WAVELENGTH_ENABLE 1): image only,
+# in hero_<case>.npz.  Same tuple as above.
+HERO_CASES = {
+    "prism": ("prism", {}, 40, 40, 4, 4, 2),
+    "mixed": ("mixed", dict(nu=64, nv=12), 48, 36, 3, 1, 3),
+}
+
 
 def scene_name(case):
     return CASES[case][0].replace("{golden}", HERE)

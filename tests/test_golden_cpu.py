@@ -6,7 +6,7 @@ import pytest
 
 from raytracer_amd import capi
 from oracle_binding import OracleScene
-from golden_cases import CASES, load, scene_name
+from golden_cases import CASES, HERO_CASES, load, scene_name
 
 
 @pytest.mark.parametrize("case", sorted(CASES))
@@ -32,6 +32,16 @@ def test_streams_and_checker_match_golden(case):
     spec, st2 = orc.render(cam, 1, 1, frames, 1)
     assert np.array_equal(spec, g["spectral"], equal_nan=True)
     assert st2["rays"] == int(g["spectral_rays"])
+
+
+@pytest.mark.parametrize("case", sorted(HERO_CASES))
+def test_checker_hero_wavelength_mode_matches_golden(case):
+    name, kw, W, H, bounces, rpp, frames = HERO_CASES[case]
+    g = load("hero_" + case)
+    cam = capi.make_camera(width=W, height=H, bounces=bounces, ray_per_pixel=rpp)
+    spec, st = OracleScene(capi.Scene(name, **kw)).render(cam, 1, 1, frames, 1, hero_wavelength=True)
+    assert np.array_equal(spec, g["spectral"], equal_nan=True)
+    assert st["rays"] == int(g["spectral_rays"])
 
 
 def test_checker_is_thread_count_invariant():

@@ -197,7 +197,7 @@ def test_ray_counts_match_checker(backend):
 
 
 # ---- committed golden vectors ------------------------------------------------------------
-from golden_cases import CASES as GOLDEN_CASES, load as load_golden, scene_name as golden_scene_name  # noqa: E402
+from golden_cases import CASES as GOLDEN_CASES, HERO_CASES, load as load_golden, scene_name as golden_scene_name  # noqa: E402
 
 
 @pytest.mark.parametrize("case", sorted(GOLDEN_CASES))
@@ -438,3 +438,71 @@ def test_spectral_area_pdf_as_written(backend, name, kw):
     want, _ = OracleScene(scene).render(cam, capi.RT_TYPE_SPECTRAL, 1, frames, 1, spectral_pdf_as_written=True)
     assert np.array_equal(got, want, equal_nan=True)
     assert not np.array_equal(got, default)
+
+
+# ---- hero-wavelength mode (the reference's HERO_WAVELENGTH_ENABLE 1) ------------------------------
+@pytest.mark.parametrize("name,kw,rpp,bounces", [("knot_glass", dict(nu=128, nv=24), 4, 4), ("prism", {}, 1, 5), ("mixed", dict(nu=96, nv=16), 4, 3),
+                                                 ("textured_room", dict(nu=64, nv=16, tex_size=32), 9, 2), ("empty", {}, 1, 0)])
+def test_hero_wavelength_mode_matches_checker(backend, name, kw, rpp, bounces):
+    """Four wavelengths per camera sample, each traced from the same seed along the same camera ray
+    (src/RayTracer.cpp:1051, 1357-1364): the backend runs its bounce loop four times per batch and
+    must land on the checker's image bit for bit, with four times the camera-ray work."""
+    W, H, frames = 56, 40, 2
+    scene, cam = _setup(backend, name, kw, W, H, bounces, rpp, capi.RT_TYPE_SPECTRAL)
+    backend.render(first_frame=1, n_frames=frames, stride=1)
+    plain, _ = backend.readback()
+    try:
+        backend.set_option(capi.RT_OPT_HERO_WAVELENGTH, 1)
+        backend.reset_accum()
+        backend.reset_stats()
+        backend.render(first_frame=1, n_frames=frames, stride=1)
+        got, n = backend.readback()
+        rays = backend.stats()["rays"]
+        # the image must not depend on how the samples are cut into batches here either
+        backend.set_option(capi.RT_OPT_MAX_PATHS, 3000)
+        backend.reset_accum()
+        backend.render(first_frame=1, n_frames=frames, stride=1)
+        small, _ = backend.readback()
+    finally:
+        backend.set_option(capi.RT_OPT_HERO_WAVELENGTH, 0)
+        backend.set_option(capi.RT_OPT_MAX_PATHS, 128 << 20)
+    want, st = OracleScene(scene).render(cam, capi.RT_TYPE_SPECTRAL, 1, frames, 1, hero_wavelength=True)
+    assert n == frames
+    assert np.array_equal(got, want, equal_nan=True), f"{int(np.any(got != want, axis=-1).sum())} differing pixels"
+    assert np.array_equal(small, got, equal_nan=True)
+    assert rays == st["rays"]
+    assert not np.array_equal(got, plain)
+
+
+@pytest.mark.parametrize("case", sorted(HERO_CASES))
+def test_gpu_hero_wavelength_mode_matches_golden(backend, case):
+    name, kw, W, H, bounces, rpp, frames = HERO_CASES[case]
+    g = load_golden("hero_" + case)
+    scene, cam = _setup(backend, name, kw, W, H, bounces, rpp, capi.RT_TYPE_SPECTRAL)
+    try:
+        backend.set_option(capi.RT_OPT_HERO_WAVELENGTH, 1)
+        backend.reset_accum()
+        backend.reset_stats()
+        backend.render(first_frame=1, n_frames=frames, stride=1)
+        got, _ = backend.readback()
+        rays = backend.stats()["rays"]
+    finally:
+        backend.set_option(capi.RT_OPT_HERO_WAVELENGTH, 0)
+    assert np.array_equal(got, g["spectral"], equal_nan=True)
+    assert rays == int(g["spectral_rays"])
+
+
+def test_hero_wavelength_option_is_ignored_by_the_rgb_integrator(backend):
+    W, H = 48, 32
+    scene, cam = _setup(backend, "cornell_knot", dict(nu=64, nv=12), W, H, 3, 4, capi.RT_TYPE_RGB)
+    backend.render(first_frame=1, n_frames=2, stride=1)
+    ref, _ = backend.readback()
+    try:
+        backend.set_option(capi.RT_OPT_HERO_WAVELENGTH, 1)
+        backend.set_frame(cam, scene.sky, capi.RT_TYPE_RGB)
+        backend.reset_accum()
+        backend.render(first_frame=1, n_frames=2, stride=1)
+        got, _ = backend.readback()
+    finally:
+        backend.set_option(capi.RT_OPT_HERO_WAVELENGTH, 0)
+    assert np.array_equal(got, ref)

@@ -270,3 +270,36 @@ def test_white_furnace():
     assert means[2] == pytest.approx(1.0, abs=1e-6)
     assert 0.98 < means[0] < 1.12
     assert 0.90 < means[1] < 1.02
+
+
+def test_hero_wavelength_mode_estimates_the_same_image():
+    """HERO_WAVELENGTH_ENABLE 1 (src/RayTracer.cpp:1357-1364) draws four wavelengths per camera
+    sample instead of one: a different estimator of the same integral.  On a matte scene lit by the
+    sky the two means agree within the noise, and with one wavelength per sample the hero mode needs
+    about four times the rays."""
+    scene = capi.Scene("furnace", nu=0)
+    orc = OracleScene(scene)
+    cam = capi.make_camera(width=24, height=18, bounces=3, ray_per_pixel=4)
+    plain, st0 = orc.render(cam, 1, 1, 32, 1)
+    hero, st1 = orc.render(cam, 1, 1, 8, 1, hero_wavelength=True)
+    assert st1["camera_samples"] * 4 == st0["camera_samples"]
+    assert 0.9 < st1["rays"] / st0["rays"] < 1.1           # 8 frames x 4 wavelengths against 32 frames
+    a, b = plain[..., :3] / 32.0, hero[..., :3] / 8.0
+    assert np.isfinite(b).all()
+    assert abs(a.mean() - b.mean()) < 0.03 * a.mean()
+    # and it is a different random sequence, not the same image
+    assert not np.array_equal(plain / 32.0, hero / 8.0)
+
+
+def test_hero_wavelengths_cover_the_range_in_quarters():
+    """get_hero_wavelengths (src/RayTracer.cpp:1259-1272): four wavelengths a quarter of the range
+    apart, wrapped into [380, 780).  Seen from outside through an emissive white quad filling the
+    view: the pixel is the mean of four CIE samples, so over many frames it tends to the white of
+    the plain mode much faster than one wavelength per sample does."""
+    scene = capi.Scene("furnace", nu=2)
+    orc = OracleScene(scene)
+    cam = capi.make_camera(width=8, height=6, bounces=1, ray_per_pixel=1)
+    plain, _ = orc.render(cam, 1, 1, 16, 1)
+    hero, _ = orc.render(cam, 1, 1, 16, 1, hero_wavelength=True)
+    sp, sh = (plain[..., :3] / 16).std(axis=(0, 1)).mean(), (hero[..., :3] / 16).std(axis=(0, 1)).mean()
+    assert sh < 0.7 * sp                                   # stratified over the spectrum: less colour noise

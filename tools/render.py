@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--ray-per-pixel", type=int, default=1)
     ap.add_argument("--bounces", type=int, default=4)
     ap.add_argument("--spectral", action="store_true")
+    ap.add_argument("--hero", action="store_true", help="Spectral with four wavelengths per camera sample (HERO_WAVELENGTH_ENABLE 1)")
     ap.add_argument("--wide", action="store_true", help="walk the opt-in four-wide trees (RT_OPT_WIDE_BVH)")
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--out", default="render.png")
@@ -42,6 +43,9 @@ def main():
     be = capi.Backend(a.device)
     if a.wide:
         be.set_option(capi.RT_OPT_WIDE_BVH, 1)
+    if a.hero:
+        a.spectral = True
+        be.set_option(capi.RT_OPT_HERO_WAVELENGTH, 1)
     be.upload_scene(scene)
     be.resize(a.width, a.height)
     be.set_frame(cam, scene.sky, capi.RT_TYPE_SPECTRAL if a.spectral else capi.RT_TYPE_RGB)
