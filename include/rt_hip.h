@@ -154,8 +154,9 @@ int rt_reset_stats(rt_ctx *ctx);
 /* Enables per-ray node/triangle visit counting (slower; off by default). */
 int rt_set_counters(rt_ctx *ctx, int enabled);
 
-/* Switches.  Only RT_OPT_SPECTRAL_PDF_AS_WRITTEN, RT_OPT_HERO_WAVELENGTH and RT_OPT_WIDE_BVH can
- * change output values; only RT_OPT_HERO_WAVELENGTH has a counterpart in the reference.
+/* Switches.  Only RT_OPT_SPECTRAL_PDF_AS_WRITTEN, RT_OPT_HERO_WAVELENGTH, RT_OPT_NEE,
+ * RT_OPT_STRATIFIED and RT_OPT_WIDE_BVH can change output values; RT_OPT_HERO_WAVELENGTH,
+ * RT_OPT_NEE and RT_OPT_STRATIFIED are the reference's shader-compile-time switches.
  *   RT_OPT_SHADOW_EARLY_OUT  RGB shadow rays stop at the first hit nearer than
  *                            distToLight - 1e-4: such a hit already fails the reference's
  *                            visibility test (src/RayTracer.cpp:439), so finishing the
@@ -189,9 +190,18 @@ int rt_set_counters(rt_ctx *ctx, int enabled);
  *                            four wavelengths, spread over the range from one random offset, along
  *                            the same camera ray and each from the same seed (it is passed by value,
  *                            src/RayTracer.cpp:1051), and adds the mean of their XYZ contributions.  Four times the rays per
- *                            sample.  Default 0, the reference's default.  Ignored by RT_TYPE_RGB. */
+ *                            sample.  Default 0, the reference's default.  Ignored by RT_TYPE_RGB.
+ *   RT_OPT_NEE               0: both integrators as built with ENABLE_NEE 0 (src/RayTracer.cpp:24,
+ *                            606): no light sampling and no shadow rays, every emitter hit counts
+ *                            in full (:357-376, :420-481, :1077-1091, :1147-1203).  Default 1.
+ *   RT_OPT_STRATIFIED        0: the RGB shader's `#else` sampling branch (src/RayTracer.cpp:584-593):
+ *                            rayPerPixel unstratified samples per frame (not floor(sqrt)^2), jitter
+ *                            over one pixel, plain mean.  Default 1 (`#if 1`, :569-583).  The
+ *                            Spectral shader has no such branch and ignores it.  Call rt_set_frame
+ *                            again after changing it. */
 enum { RT_OPT_SHADOW_EARLY_OUT = 1, RT_OPT_REFILL_LANES = 2, RT_OPT_INNER_SHARE = 3, RT_OPT_MAX_PATHS = 4, RT_OPT_TILE_MAJOR = 5,
-       RT_OPT_SPECTRAL_PDF_AS_WRITTEN = 6, RT_OPT_WIDE_BVH = 7, RT_OPT_HERO_WAVELENGTH = 8 };
+       RT_OPT_SPECTRAL_PDF_AS_WRITTEN = 6, RT_OPT_WIDE_BVH = 7, RT_OPT_HERO_WAVELENGTH = 8, RT_OPT_NEE = 9,
+       RT_OPT_STRATIFIED = 10 };
 int rt_set_option(rt_ctx *ctx, int option, int value);
 
 const char *rt_strerror(int status);

@@ -90,6 +90,8 @@ struct Ctx {
     // Spectral shader text has it (type bit 8 of orc_render); default is the RGB convention.
     bool spectralPdfAsWritten = false;
     bool heroWavelength = false;   // HERO_WAVELENGTH_ENABLE 1 (src/RayTracer.cpp:607, 1357-1364)
+    bool nee = true;               // ENABLE_NEE (src/RayTracer.cpp:24, 606); false = the shaders built with 0
+    bool stratified = true;        // `#if 1` of the RGB main (src/RayTracer.cpp:569); false = its #else branch
 };
 
 // ---- GLSL structs (src/RayTracer.cpp:43-88, src/RayScene.cpp:215-257) -------------
@@ -744,7 +746,7 @@ static V3 traceColor(Ctx &c, Ray r, uint32_t &seed) {
         if (!info.front_face) N = -N;
 
         if (dot(info.mat.emissionColor, info.mat.emissionColor) > 0.0f && info.mat.emissionStrength > 0.0f) {
-            if (i == 0) {
+            if (i == 0 || !c.nee) {   // #else branch of ENABLE_NEE, :374-376: the same expression
                 incomingLight = incomingLight + rayColor * info.mat.emissionColor * info.mat.emissionStrength;
             } else {
                 float w_brdf;
@@ -798,7 +800,7 @@ static V3 traceColor(Ctx &c, Ray r, uint32_t &seed) {
         float VoH = rtm::clamp_(dot(V, H), 0.0f, 1.0f);
         float LoV = rtm::clamp_(dot(L, V), 0.0f, 1.0f);
 
-        if (trans == 0) {
+        if (trans == 0 && c.nee) {   // the block is compiled out with ENABLE_NEE 0, :420-481
             float area, lightTriangleCount;
             V3 p = sampleRandomPointFromLightSouces(c, seed, area, lightTriangleCount);
             if (area > 0.0f) {
@@ -929,6 +931,21 @@ static V3 framePixel(Ctx &c, int px, int py, int type) {
     float rssq = 1.0f / (float)ssq;
     float wl_dt = WL_RANGE / (float)c.cam.rayPerPixel;
     float wl_pdf = 1.0f / WL_RANGE;
+    if (type == 0 && !c.stratified) {
+        // src/RayTracer.cpp:584-593: rayPerPixel unstratified samples, jitter of one pixel, plain mean.
+        for (int i = 0; i < c.cam.rayPerPixel; ++i) {
+            uint32_t seed = rtm::hash_seed((uint32_t)px, (uint32_t)py, c.frameCount, (uint32_t)i);
+            Ray r;
+            r.origin = b.cameraCenter;
+            float jx = rtm::rand_float(seed);  // U7: first draw feeds the horizontal jitter
+            float jy = rtm::rand_float(seed);
+            V3 d = b.uv + jx * b.rImgX * b.right + jy * b.rImgY * b.up;
+            r.direction = normalize(d - b.cameraCenter);
+            c.cnt.cameraSamples++;
+            color = color + traceColor(c, r, seed);
+        }
+        return color / (float)c.cam.rayPerPixel;
+    }
     for (int i = 0; i < ssq; ++i) {
         for (int j = 0; j < ssq; ++j) {
             uint32_t seed = rtm::hash_seed((uint32_t)px, (uint32_t)py, c.frameCount, (uint32_t)(j + i * ssq));
@@ -1058,6 +1075,8 @@ int orc_render(const orc_scene *s, const Camera *cam, const float sky[3], int ty
         Ctx c{&s->sc, *cam, v3(sky[0], sky[1], sky[2]), 0u, Counters()};
         c.spectralPdfAsWritten = (typeAndFlags & 0x100) != 0;
         c.heroWavelength = (typeAndFlags & 0x200) != 0;
+        c.nee = (typeAndFlags & 0x400) == 0;
+        c.stratified = (typeAndFlags & 0x800) == 0;
         for (int x = x0; x < x1; ++x) {
             size_t at = ((size_t)y * W + x) * 4;
             for (uint32_t k = 0; k < n_frames; ++k) {

@@ -17,6 +17,8 @@ RT_TYPE_RGB, RT_TYPE_SPECTRAL = 0, 1
 RT_OPT_SHADOW_EARLY_OUT, RT_OPT_REFILL_LANES, RT_OPT_INNER_SHARE, RT_OPT_MAX_PATHS, RT_OPT_TILE_MAJOR, RT_OPT_SPECTRAL_PDF_AS_WRITTEN = 1, 2, 3, 4, 5, 6
 RT_OPT_WIDE_BVH = 7
 RT_OPT_HERO_WAVELENGTH = 8
+RT_OPT_NEE = 9
+RT_OPT_STRATIFIED = 10
 
 # Every symbol include/rt_hip.h declares.
 HIP_SYMBOLS = [

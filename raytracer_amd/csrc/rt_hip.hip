@@ -83,6 +83,8 @@ struct FrameParams {
     int32_t shadowEarlyOut;   // RGB shadow rays stop at the first hit that already proves occlusion
     int32_t spectralPdfAsWritten;   // Spectral: area pdf without the light-selection probability
     int32_t hero;             // Spectral: four wavelengths per camera sample (HERO_WAVELENGTH_ENABLE, src/RayTracer.cpp:607)
+    int32_t nee;              // next-event estimation on (ENABLE_NEE, src/RayTracer.cpp:24, 606)
+    int32_t stratified;       // RGB: stratified samples (`#if 1`, src/RayTracer.cpp:569); 0 = its #else branch, S = rayPerPixel
     // Tile-split sharding: this context renders only the 8x8 tiles whose row-major
     // index i satisfies i % tileStride == tileOffset (all tiles when stride is 1).
     uint32_t tileOffset, tileStride;
@@ -220,6 +222,7 @@ __global__ __launch_bounds__(kBlock) void k_generate(FrameParams fp, Batch bt, P
                 float jx = rand_float(seed);
                 float jy = rand_float(seed);
                 V3 d = uv + (((float)j + jx) * fp.rssq) * fp.rImgX * fp.right + (((float)i + jy) * fp.rssq) * fp.rImgY * fp.up;
+                if (!SPECTRAL && !fp.stratified) d = uv + jx * fp.rImgX * fp.right + jy * fp.rImgY * fp.up;   // :589
                 d = normalize(d - fp.position);
 
                 RayRec r;
@@ -951,7 +954,7 @@ __global__ __launch_bounds__(kBlock, RT_SHADE_BLOCKS) void k_shade_rgb(SceneView
                 const MaterialD &mat = info.mat;
 
                 if (dot(mat.emissionColor, mat.emissionColor) > 0.0f && mat.emissionStrength > 0.0f) {   // :356-378
-                    if (stage == 0) {
+                    if (stage == 0 || !fp.nee) {   // without NEE every emitter hit counts in full (:374-376, :1089-1091)
                         incoming = incoming + rayColor * mat.emissionColor * mat.emissionStrength;
                     } else {
                         float wBrdf;
@@ -997,7 +1000,7 @@ __global__ __launch_bounds__(kBlock, RT_SHADE_BLOCKS) void k_shade_rgb(SceneView
                     const float VoH = clamp_(dot(V, H), 0.0f, 1.0f);
                     const float LoV = clamp_(dot(L, V), 0.0f, 1.0f);
 
-                    if (!trans) {                                   // NEE set-up, :421-437
+                    if (!trans && fp.nee) {                         // NEE set-up, :421-437 (compiled out with ENABLE_NEE 0)
                         float area, lightTriangleCount;
                         V3 p = sampleLightPoint(sc, seed, area, lightTriangleCount);
                         if (area > 0.0f) {
@@ -1126,7 +1129,7 @@ __global__ __launch_bounds__(kBlock) void k_shade_spectral(SceneView sc, FramePa
 
                 if (dot(mat.emissionColor, mat.emissionColor) > 0.0f && mat.emissionStrength > 0.0f) {   // :1075-1093
                     float energy = reflectanceAt(lambda, mat.emissionColor);
-                    if (stage == 0) {
+                    if (stage == 0 || !fp.nee) {   // without NEE every emitter hit counts in full (:374-376, :1089-1091)
                         radiance += energy * throughput * mat.emissionStrength;
                     } else {
                         float wBrdf;
@@ -1181,7 +1184,7 @@ __global__ __launch_bounds__(kBlock) void k_shade_spectral(SceneView sc, FramePa
                     surf.specular = mat.specular;
                     surf.specularTint = mat.specularTint;
 
-                    if (!trans) {                                   // :1148-1160 (no cosTheta gate here)
+                    if (!trans && fp.nee) {                         // :1148-1160 (no cosTheta gate here; compiled out with ENABLE_NEE 0)
                         float area, lightTriangleCount;
                         V3 p = sampleLightPoint(sc, seed, area, lightTriangleCount);
                         if (area > 0.0f) {
@@ -1303,7 +1306,7 @@ __global__ __launch_bounds__(kBlock) void k_resolve(FrameParams fp, Batch bt, Pa
                 c = c + v3(sB.x, sB.y, sB.z);
             }
             if (s == fp.S - 1u) {
-                V3 col = c * (fp.rssq * fp.rssq);
+                V3 col = (!SPECTRAL && !fp.stratified) ? c / (float)fp.rayPerPixel : c * (fp.rssq * fp.rssq);   // :592 / :582
                 if (SPECTRAL) {
                     col = col / kCieYIntegral;
                     col = xyzEToLinearSRGB(col);
@@ -1389,6 +1392,8 @@ struct rt_ctx {
     bool shadowEarlyOut = true;
     bool spectralPdfAsWritten = false;
     bool heroWavelength = false;
+    bool nee = true;
+    bool stratified = true;
     uint32_t tileOffset = 0, tileStride = 1;
     bool planesInner = true;   // tile-major path order inside a batch
     int refillLanes = 32;   // idle lanes that trigger a refill for stages > 0
@@ -1888,7 +1893,7 @@ int runBatch(rt_ctx *ctx, const Batch &bt) {
 
         for (int b = 0; b <= fp.bounces; ++b) {
             launchTrace(ctx, b & 1, b);
-            if (b > 0) {
+            if (b > 0 && fp.nee) {   // without NEE there are no shadow rays to connect
                 if (spectral) hipLaunchKernelGGL(k_connect<true>, dim3(gShade), dim3(kBlock), 0, ctx->stream, ctx->view, bt, ctx->pb, b, cnt, fp.shadowEarlyOut);
                 else hipLaunchKernelGGL(k_connect<false>, dim3(gShade), dim3(kBlock), 0, ctx->stream, ctx->view, bt, ctx->pb, b, cnt, fp.shadowEarlyOut);
             }
@@ -1896,9 +1901,11 @@ int runBatch(rt_ctx *ctx, const Batch &bt) {
             else hipLaunchKernelGGL(k_shade_rgb, dim3(gShade), dim3(kBlock), 0, ctx->stream, ctx->view, fp, bt, ctx->pb, b, cnt);
         }
         const int last = fp.bounces + 1;
-        launchTrace(ctx, -1, last);
-        if (spectral) hipLaunchKernelGGL(k_connect<true>, dim3(gShade), dim3(kBlock), 0, ctx->stream, ctx->view, bt, ctx->pb, last, cnt, fp.shadowEarlyOut);
-        else hipLaunchKernelGGL(k_connect<false>, dim3(gShade), dim3(kBlock), 0, ctx->stream, ctx->view, bt, ctx->pb, last, cnt, fp.shadowEarlyOut);
+        if (fp.nee) {
+            launchTrace(ctx, -1, last);
+            if (spectral) hipLaunchKernelGGL(k_connect<true>, dim3(gShade), dim3(kBlock), 0, ctx->stream, ctx->view, bt, ctx->pb, last, cnt, fp.shadowEarlyOut);
+            else hipLaunchKernelGGL(k_connect<false>, dim3(gShade), dim3(kBlock), 0, ctx->stream, ctx->view, bt, ctx->pb, last, cnt, fp.shadowEarlyOut);
+        }
     }
 
     const int gRes = gridFor(ctx, fp.npt, 16);
@@ -2205,9 +2212,12 @@ int rt_set_frame(rt_ctx *ctx, const rt_camera *cam, const float sky_linear[3], i
     fp.tilesY = (ctx->H + 7) / 8;
     fp.npt = (uint32_t)fp.tilesX * (uint32_t)fp.tilesY * 64u;
     fp.S = (uint32_t)fp.ssq * (uint32_t)fp.ssq;
+    fp.stratified = (ctx->stratified || type != RT_TYPE_RGB) ? 1 : 0;
+    if (!fp.stratified) fp.S = (uint32_t)fp.rayPerPixel;
     fp.shadowEarlyOut = (ctx->shadowEarlyOut && type == RT_TYPE_RGB) ? 1 : 0;
     fp.spectralPdfAsWritten = ctx->spectralPdfAsWritten ? 1 : 0;
     fp.hero = (ctx->heroWavelength && type == RT_TYPE_SPECTRAL) ? 1 : 0;
+    fp.nee = ctx->nee ? 1 : 0;
     fp.tileOffset = ctx->tileOffset;
     fp.tileStride = ctx->tileStride;
     ctx->type = type;
@@ -2449,6 +2459,15 @@ int rt_set_option(rt_ctx *ctx, int option, int value) {
         case RT_OPT_SPECTRAL_PDF_AS_WRITTEN:
             ctx->spectralPdfAsWritten = value != 0;
             ctx->fp.spectralPdfAsWritten = value != 0 ? 1 : 0;
+            return RT_OK;
+        case RT_OPT_STRATIFIED:
+            // changes the number of samples per frame: takes effect at the next rt_set_frame
+            ctx->stratified = value != 0;
+            ctx->frameSet = false;
+            return RT_OK;
+        case RT_OPT_NEE:
+            ctx->nee = value != 0;
+            ctx->fp.nee = ctx->nee ? 1 : 0;
             return RT_OK;
         case RT_OPT_HERO_WAVELENGTH:
             ctx->heroWavelength = value != 0;

@@ -60,14 +60,14 @@ class OracleScene:
         assert rc == 0
         return model, ident, t, u, v, {"rays": counters[0], "node_visits": counters[1], "tri_tests": counters[2]}
 
-    def render(self, cam, rtype=0, first_frame=1, n_frames=1, stride=1, region=None, threads=THREADS, want_mean=False, spectral_pdf_as_written=False, hero_wavelength=False):
+    def render(self, cam, rtype=0, first_frame=1, n_frames=1, stride=1, region=None, threads=THREADS, want_mean=False, spectral_pdf_as_written=False, hero_wavelength=False, nee=True, stratified=True):
         W, H = int(cam.resolution[0]), int(cam.resolution[1])
         x0, y0, x1, y1 = region or (0, 0, W, H)
         rgba = np.zeros((H, W, 4), np.float32)
         mean = np.zeros((H, W, 4), np.float32) if want_mean else None
         stats = (C.c_uint64 * 5)()
         sky = (C.c_float * 3)(*[float(s) for s in self.sky])
-        rc = lib.orc_render(self._h, C.byref(cam), sky, rtype | (0x100 if spectral_pdf_as_written else 0) | (0x200 if hero_wavelength else 0), first_frame, n_frames, stride, x0, y0, x1, y1, rgba.ctypes.data_as(_vp),
+        rc = lib.orc_render(self._h, C.byref(cam), sky, rtype | (0x100 if spectral_pdf_as_written else 0) | (0x200 if hero_wavelength else 0) | (0 if nee else 0x400) | (0 if stratified else 0x800), first_frame, n_frames, stride, x0, y0, x1, y1, rgba.ctypes.data_as(_vp),
                             mean.ctypes.data_as(_vp) if want_mean else None, stats, threads)
         assert rc == 0
         st = dict(zip(["rays", "node_visits", "tri_tests", "shaded_hits", "camera_samples"], list(stats)))

@@ -506,3 +506,65 @@ def test_hero_wavelength_option_is_ignored_by_the_rgb_integrator(backend):
     finally:
         backend.set_option(capi.RT_OPT_HERO_WAVELENGTH, 0)
     assert np.array_equal(got, ref)
+
+
+# ---- the reference's ENABLE_NEE 0 build --------------------------------------------------------------
+@pytest.mark.parametrize("rtype", [capi.RT_TYPE_RGB, capi.RT_TYPE_SPECTRAL])
+@pytest.mark.parametrize("name,kw", [("cornell_knot", dict(nu=96, nv=16)), ("mixed", dict(nu=96, nv=16)), ("roughness_demo", {})])
+def test_without_next_event_estimation(backend, name, kw, rtype):
+    """Both integrators as compiled with ENABLE_NEE 0 (src/RayTracer.cpp:24, 606): no light sampling,
+    no shadow rays, emitters count in full when a path runs into them.  Same image as the checker
+    bit for bit, fewer rays than with NEE, and a different image."""
+    W, H, frames = 56, 40, 2
+    scene, cam = _setup(backend, name, kw, W, H, 4, 4, rtype)
+    backend.reset_stats()
+    backend.render(first_frame=1, n_frames=frames, stride=1)
+    with_nee, _ = backend.readback()
+    rays_with = backend.stats()["rays"]
+    try:
+        backend.set_option(capi.RT_OPT_NEE, 0)
+        backend.reset_accum()
+        backend.reset_stats()
+        backend.render(first_frame=1, n_frames=frames, stride=1)
+        got, _ = backend.readback()
+        rays = backend.stats()["rays"]
+    finally:
+        backend.set_option(capi.RT_OPT_NEE, 1)
+    want, st = OracleScene(scene).render(cam, rtype, 1, frames, 1, nee=False)
+    assert np.array_equal(got, want, equal_nan=True), f"{int(np.any(got != want, axis=-1).sum())} differing pixels"
+    assert rays == st["rays"]
+    if scene.light_sources_count > 0:
+        assert rays < rays_with
+        assert not np.array_equal(got, with_nee)
+
+
+# ---- the RGB shader's unstratified sampling branch ------------------------------------------------------
+@pytest.mark.parametrize("name,kw,rpp", [("cornell_knot", dict(nu=96, nv=16), 5), ("mixed", dict(nu=96, nv=16), 4), ("roughness_demo", {}, 1)])
+def test_unstratified_sampling_branch(backend, name, kw, rpp):
+    """`#else` of the RGB main (src/RayTracer.cpp:584-593): rayPerPixel samples per frame (5 stays 5,
+    the stratified branch would take 4), jitter over one pixel, plain mean.  Bit-identical to the
+    checker, also when the samples of a frame are cut into several batches."""
+    W, H, frames = 56, 40, 3
+    scene, cam = _setup(backend, name, kw, W, H, 3, rpp, capi.RT_TYPE_RGB)
+    try:
+        backend.set_option(capi.RT_OPT_STRATIFIED, 0)
+        with pytest.raises(capi.RtError):
+            backend.render(first_frame=1, n_frames=1, stride=1)      # the frame must be set again
+        backend.set_frame(cam, scene.sky, capi.RT_TYPE_RGB)
+        backend.reset_accum()
+        backend.reset_stats()
+        backend.render(first_frame=1, n_frames=frames, stride=1)
+        got, n = backend.readback()
+        samples = backend.stats()["camera_samples"]
+        backend.set_option(capi.RT_OPT_MAX_PATHS, 3000)
+        backend.reset_accum()
+        backend.render(first_frame=1, n_frames=frames, stride=1)
+        small, _ = backend.readback()
+    finally:
+        backend.set_option(capi.RT_OPT_STRATIFIED, 1)
+        backend.set_option(capi.RT_OPT_MAX_PATHS, 128 << 20)
+        backend.set_frame(cam, scene.sky, capi.RT_TYPE_RGB)
+    want, st = OracleScene(scene).render(cam, capi.RT_TYPE_RGB, 1, frames, 1, stratified=False)
+    assert n == frames and samples == W * H * rpp * frames == st["camera_samples"]
+    assert np.array_equal(got, want, equal_nan=True), f"{int(np.any(got != want, axis=-1).sum())} differing pixels"
+    assert np.array_equal(small, got, equal_nan=True)

@@ -303,3 +303,17 @@ def test_hero_wavelengths_cover_the_range_in_quarters():
     hero, _ = orc.render(cam, 1, 1, 16, 1, hero_wavelength=True)
     sp, sh = (plain[..., :3] / 16).std(axis=(0, 1)).mean(), (hero[..., :3] / 16).std(axis=(0, 1)).mean()
     assert sh < 0.7 * sp                                   # stratified over the spectrum: less colour noise
+
+
+def test_without_nee_the_estimate_is_the_same_but_noisier():
+    """ENABLE_NEE 0 (src/RayTracer.cpp:24): paths find the light only by running into it.  Same
+    expectation as with NEE + MIS, much more variance; no shadow rays."""
+    scene = capi.Scene("cornell_knot", nu=32, nv=8)      # the light is a model: only those are light-sampled
+    orc = OracleScene(scene)
+    cam = capi.make_camera(width=24, height=18, bounces=4, ray_per_pixel=4)
+    a, st_a = orc.render(cam, 0, 1, 48, 1)
+    b, st_b = orc.render(cam, 0, 1, 48, 1, nee=False)
+    assert st_b["rays"] < st_a["rays"]
+    ma, mb = a[..., :3].mean() / 48, b[..., :3].mean() / 48
+    assert abs(ma - mb) < 0.15 * ma
+    assert (b[..., :3] / 48).std() > (a[..., :3] / 48).std()
