@@ -37,16 +37,21 @@ def main():
         be.resize(w, h)
         orc = OracleScene(scene)
         for rtype in (capi.RT_TYPE_RGB, capi.RT_TYPE_SPECTRAL):
+            # the reference's shader-compile-time switches, at random (one scene in four each)
+            nee, strat, hero = bool(rng.integers(0, 4)), bool(rng.integers(0, 4)), not rng.integers(0, 4)
+            be.set_option(capi.RT_OPT_NEE, int(nee))
+            be.set_option(capi.RT_OPT_STRATIFIED, int(strat))
+            be.set_option(capi.RT_OPT_HERO_WAVELENGTH, int(hero))
             be.set_frame(cam, scene.sky, rtype)
             be.reset_accum()
             frame = int(rng.integers(1, 1 << 20))
             be.render(first_frame=frame, n_frames=2, stride=3)
             got, _ = be.readback()
-            want, _ = orc.render(cam, rtype, frame, 2, 3)
+            want, _ = orc.render(cam, rtype, frame, 2, 3, nee=nee, stratified=strat, hero_wavelength=hero)
             if not np.array_equal(got, want, equal_nan=True):
                 bad += 1
                 diff = np.argwhere(np.any((got != want) & ~(np.isnan(got) & np.isnan(want)), axis=-1))
-                print(f"MISMATCH seed={seed} type={rtype} nu={nu} {w}x{h} bounces={bounces} rpp={rpp}: {len(diff)} pixels, first {diff[0]}", flush=True)
+                print(f"MISMATCH seed={seed} type={rtype} nu={nu} {w}x{h} bounces={bounces} rpp={rpp} nee={nee} stratified={strat} hero={hero}: {len(diff)} pixels, first {diff[0]}", flush=True)
         scene.close()
     be.close()
     print(f"{count} scenes x 2 integrators: {bad} mismatches")
