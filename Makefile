@@ -22,7 +22,7 @@ HOST_HDRS := $(wildcard $(HOST)/*.h $(HOST)/gpu/*.h $(HOST)/glm/*.hpp $(HOST)/gl
 
 all: $(LIBDIR)/librt_hip.so $(LIBDIR)/librt_host.so oracle/liboracle.so examples/rt_render
 
-$(LIBDIR)/librt_hip.so: $(CSRC)/rt_hip.hip $(CSRC)/rt_device.h $(CSRC)/rt_bsdf.h $(CSRC)/rt_math.h include/rt_hip.h
+$(LIBDIR)/librt_hip.so: $(CSRC)/rt_hip.hip $(wildcard $(CSRC)/*.h) include/rt_hip.h
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -shared $(CSRC)/rt_hip.hip -o $@
 

@@ -21,6 +21,10 @@
 // hitModel (reference src/RayScene.cpp:681-736), so the winner of a distance
 // tie is the one the reference would report.
 //
+// This file is the host side (context, scene commit and re-pack, launches, RCCL); the kernels are in
+// rt_kernels_frame.h, rt_kernels_trace.h and rt_kernels_shade.h, their shared state in
+// rt_wavefront.h, scene decode and BSDFs in rt_device.h / rt_bsdf.h, pinned math in rt_math.h.
+//
 // Build with -ffp-contract=off (see rt_math.h).
 
 #include <hip/hip_runtime.h>
@@ -40,1312 +44,10 @@
 
 using namespace rtd;
 
-namespace {
-
-#ifndef RT_W20
-#define RT_W20 7
-#endif
-#ifndef RT_WALPHA
-#define RT_WALPHA 6   // alpha-cut variants: 80 VGPRs; at 7 waves/SIMD (72) they spill inside the main loop
-#endif
-#ifndef RT_WWIDE
-#define RT_WWIDE 7     // waves/SIMD of the four-wide variants (72 VGPRs with 40 B of spills: +4 % over 6 waves without)
-#endif
-#ifndef RT_WWIDE_ALPHA
-#define RT_WWIDE_ALPHA 5
-#endif
-constexpr int kStackDepth = 32;      // int stack[32], src/RayScene.cpp:682
-#ifndef RT_WSTACK
-#define RT_WSTACK 16
-#endif
-constexpr int kWideStack = RT_WSTACK;   // LDS stack entries of the four-wide variants; deeper entries go to memory
-constexpr int kBlock = 256;
-constexpr int kMaxBounces = 62;      // stages kept on the device
-// Default ceiling of paths in flight per batch (~190 B of device memory each).  Every kernel of
-// a batch ends with a drain tail in which most of the chip idles, so few large batches beat many
-// small ones: the default bench step (1920x1080 x 64 sample planes) fits in one batch.
-constexpr uint32_t kDefaultMaxPaths = 128u << 20;
-constexpr float kNeverStop = -1e30f;  // RayRec::pad1 of rays that must find their closest hit
-
-// Per-frame uniforms plus values derived from them once on the host.
-struct FrameParams {
-    float fov, resX, resY;
-    V3 position, forward, right, up;
-    int32_t bounces, rayPerPixel;
-    V3 sky;
-    // fragment main(), src/RayTracer.cpp:545-563
-    float rImgX, rImgY, focalLength, halfWidth, halfHeight;
-    int32_t ssq;
-    float rssq, wlDt, wlPdf;
-    int32_t W, H, tilesX, tilesY;
-    uint32_t npt;       // padded pixels per sample plane: tilesX*tilesY*64
-    uint32_t S;         // samples per frame = ssq*ssq
-    int32_t shadowEarlyOut;   // RGB shadow rays stop at the first hit that already proves occlusion
-    int32_t spectralPdfAsWritten;   // Spectral: area pdf without the light-selection probability
-    int32_t hero;             // Spectral: four wavelengths per camera sample (HERO_WAVELENGTH_ENABLE, src/RayTracer.cpp:607)
-    int32_t nee;              // next-event estimation on (ENABLE_NEE, src/RayTracer.cpp:24, 606)
-    int32_t stratified;       // RGB: stratified samples (`#if 1`, src/RayTracer.cpp:569); 0 = its #else branch, S = rayPerPixel
-    // Tile-split sharding: this context renders only the 8x8 tiles whose row-major
-    // index i satisfies i % tileStride == tileOffset (all tiles when stride is 1).
-    uint32_t tileOffset, tileStride;
-};
-
-struct Batch {
-    uint32_t g0;         // first global sample index (frame-major, sample-minor)
-    uint32_t K;          // sample planes in this batch
-    uint32_t firstFrame, frameStride;
-    uint32_t P;          // capacity in paths; shadow-ray slots start at P
-    uint32_t planesInner;   // path order: 1 = tile-major (all K samples of a tile adjacent), 0 = plane-major
-};
-
-// Path index of sample plane k (0..K-1) of padded pixel q.  Tile-major order keeps the rays in
-// flight at any moment inside a small screen region, so they share the tree nodes they open.
-__device__ __forceinline__ uint32_t pathIndex(const FrameParams &fp, const Batch &bt, uint32_t k, uint32_t q);
-
-
-// Every ray queue is split into kSubQueues sub-queues, each with its length and
-// its consumer cursor on a 128-byte line of its own: a single queue word would
-// take one atomic per wave from every CU and saturates at ~90 atomics/us.
-// Block b of any producer/consumer kernel owns sub-queue b % kSubQueues; the
-// persistent traversal kernel drains all of them.
-#ifndef RT_SUBQ
-#define RT_SUBQ 32
-#endif
-constexpr int kSubQueues = RT_SUBQ;
-static_assert(2 * kSubQueues <= 64, "the traversal kernel scans all sources with one wave-wide load");
-struct __attribute__((aligned(128))) SubQueue {
-    uint32_t count;      // entries appended by the producer kernel
-    uint32_t cursor;     // next entry the traversal kernel hands out
-    uint32_t pad[30];
-};
-// Queues of one bounce, all device resident.
-struct Stage {
-    SubQueue ext[kSubQueues];      // extension rays entering this bounce
-    SubQueue shadow[kSubQueues];   // shadow rays produced by the previous bounce
-};
-
-struct PathBuffers {
-    RayRec *rays;        // [2P]  extension rays [0,P), shadow rays [P,2P)
-    HitRec *hits;        // [2P]
-    float4 *stA;         // [P]   RGB: throughput.rgb, prevBrdfPdf      Spectral: throughput, prevBrdfPdf, lambda, -
-    float4 *stB;         // [P]   RGB: radiance.rgb, seed bits          Spectral: radiance, -, -, seed bits
-    float4 *neeA, *neeB, *neeC;   // [P] pending NEE term of the current bounce
-    uint32_t *qExt[2];   // [kSubQueues * subCap] each, ping-pong by bounce parity
-    uint32_t *qShadow;   // [kSubQueues * subCap]
-    uint32_t subCap;     // capacity of one sub-queue
-    Stage *stages;       // [kMaxBounces + 2]
-    unsigned long long *counters;  // [8]: 0 rays, 1 nodeVisits, 2 triTests, 3 shadedHits, 4 deepest traversal stack
-    // Four-wide traversal only: stack entries beyond the LDS part, [wave][overflowDepth][64].
-    int32_t *overflow;
-    uint32_t overflowDepth;
-};
-
-__device__ __forceinline__ uint32_t laneId() { return threadIdx.x & 63u; }
-// The lane number from the execution-mask counters; volatile, so every use re-reads it.
-__device__ __forceinline__ uint32_t laneIdNow() {
-    uint32_t x;
-    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(x));
-    return x;
-}
-
-// Appends `value` for every lane with `want`; one atomic per wave.  Must be
-// called by all lanes of the wave.
-__device__ __forceinline__ void wavePush(bool want, uint32_t *queue, uint32_t *count, uint32_t value) {
-    unsigned long long mask = __ballot(want);
-    if (mask == 0ull) return;
-    uint32_t lane = laneId();
-    int leader = __ffsll((long long)mask) - 1;
-    uint32_t base = 0;
-    if ((int)lane == leader) base = atomicAdd(count, (uint32_t)__popcll(mask));
-    base = __shfl(base, leader);
-    if (want) queue[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = value;
-}
-
-// Path index -> pixel.  64 consecutive paths form one 8x8 pixel tile so a wave
-// of primary rays is spatially compact.
-__device__ __forceinline__ bool pathPixel(const FrameParams &fp, uint32_t q, int &x, int &y) {
-    uint32_t tile = q >> 6, l = q & 63u;
-    x = (int)(tile % (uint32_t)fp.tilesX) * 8 + (int)(l & 7u);
-    y = (int)(tile / (uint32_t)fp.tilesX) * 8 + (int)(l >> 3);
-    return x < fp.W && y < fp.H && (tile % fp.tileStride) == fp.tileOffset;
-}
-
-__device__ __forceinline__ uint32_t pathIndex(const FrameParams &fp, const Batch &bt, uint32_t k, uint32_t q) {
-    return bt.planesInner ? ((((q >> 6) * bt.K + k) << 6) | (q & 63u)) : k * fp.npt + q;
-}
-
-// ---- k_generate -----------------------------------------------------------------------
-// Camera ray of fragment main() (src/RayTracer.cpp:559-578 / 1333-1366): jitter
-// in units of (1/W)*right and (1/H)*up, first draw horizontal.
-//
-// Hero-wavelength mode (src/RayTracer.cpp:1357-1364) traces four wavelengths per camera sample one
-// after the other along the same camera ray, each from the same seed: the batch runs the bounce
-// loop four times, and this kernel starts pass `heroPass` (0..3; -1 = mode off).  Passes after the
-// first fold the finished wavelength into the sample's XYZ sum (kept in neeC, which the Spectral
-// integrator does not otherwise use) and restart the path.
-// get_hero_wavelengths, src/RayTracer.cpp:1259-1272, one component; mod(x, y) = x - y*floor(x/y).
-__device__ __forceinline__ float heroWavelength(int k, float baseOffset) {
-    const float stride = kWlRange / 4.0f;
-    const float x = (kWlMin + stride * ((float)k + baseOffset)) - kWlMin;
-    return (x - kWlRange * floor_(x / kWlRange)) + kWlMin;
-}
-
-template <bool SPECTRAL>
-__global__ __launch_bounds__(kBlock) void k_generate(FrameParams fp, Batch bt, PathBuffers pb, int heroPass) {
-    const uint32_t total = bt.K * fp.npt;
-    const uint32_t stride = gridDim.x * kBlock;
-    for (uint32_t base = blockIdx.x * kBlock + (threadIdx.x & ~63u); base < total; base += stride) {
-        uint32_t p = base + laneId();
-        bool valid = false;
-        if (p < total) {
-            uint32_t k, q;
-            if (bt.planesInner) {
-                const uint32_t w = p >> 6;
-                k = w % bt.K;
-                q = ((w / bt.K) << 6) | (p & 63u);
-            } else {
-                k = p / fp.npt;
-                q = p - k * fp.npt;
-            }
-            int x, y;
-            valid = pathPixel(fp, q, x, y);
-            if (valid) {
-                uint32_t g = bt.g0 + k;
-                uint32_t frame = bt.firstFrame + (g / fp.S) * bt.frameStride;
-                uint32_t s = g % fp.S;
-                int i = (int)(s / (uint32_t)fp.ssq), j = (int)(s % (uint32_t)fp.ssq);
-                uint32_t seed = hash_seed((uint32_t)x, (uint32_t)y, frame, s);
-
-                float ux = (float)x * fp.rImgX * 2.0f - 1.0f;
-                float uy = (float)y * fp.rImgY * 2.0f - 1.0f;
-                V3 uv = fp.halfWidth * ux * fp.right + fp.halfHeight * uy * fp.up + fp.focalLength * fp.forward + fp.position;
-                float jx = rand_float(seed);
-                float jy = rand_float(seed);
-                V3 d = uv + (((float)j + jx) * fp.rssq) * fp.rImgX * fp.right + (((float)i + jy) * fp.rssq) * fp.rImgY * fp.up;
-                if (!SPECTRAL && !fp.stratified) d = uv + jx * fp.rImgX * fp.right + jy * fp.rImgY * fp.up;   // :589
-                d = normalize(d - fp.position);
-
-                RayRec r;
-                r.ox = fp.position.x; r.oy = fp.position.y; r.oz = fp.position.z; r.pad0 = 0.0f;
-                r.dx = d.x; r.dy = d.y; r.dz = d.z; r.pad1 = kNeverStop;
-                pb.rays[p] = r;
-                if (SPECTRAL && heroPass >= 0) {
-                    // The seed is passed to traceColorWavelength by value (src/RayTracer.cpp:1051), so
-                    // every wavelength of the sample starts from the same state: the one after this draw.
-                    const float baseOffset = (rand_float(seed) + (float)(i * fp.ssq) + (float)j) * fp.wlDt;
-                    float4 sum = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                    if (heroPass > 0) {
-                        sum = pb.neeC[p];
-                        const V3 xyz = v3(sum.x, sum.y, sum.z) + cieXYZ(pb.stA[p].z) * (pb.stB[p].x / fp.wlPdf);
-                        sum = make_float4(xyz.x, xyz.y, xyz.z, 0.0f);
-                    }
-                    pb.neeC[p] = sum;
-                    pb.stA[p] = make_float4(1.0f, 1.0f, heroWavelength(heroPass, baseOffset), 0.0f);
-                    pb.stB[p] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(seed));
-                } else if (SPECTRAL) {
-                    float lambda = (rand_float(seed) + (float)(i * fp.ssq) + (float)j) * fp.wlDt + kWlMin;
-                    pb.stA[p] = make_float4(1.0f, 1.0f, lambda, 0.0f);
-                    pb.stB[p] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(seed));
-                } else {
-                    pb.stA[p] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
-                    pb.stB[p] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(seed));
-                }
-            }
-        }
-        const uint32_t sub = blockIdx.x % kSubQueues;
-        wavePush(valid, pb.qExt[0] + (size_t)sub * pb.subCap, &pb.stages[0].ext[sub].count, p);
-    }
-}
-
-// ---- k_trace ----------------------------------------------------------------------------
-// RayBoundingBoxDst, src/RayScene.cpp:417-431, with 1/direction hoisted per ray.
-__device__ __forceinline__ float slabDistance(V3 bmin, V3 bmax, V3 ro, V3 inv, float t) {
-    V3 tMin = (bmin - ro) * inv;
-    V3 tMax = (bmax - ro) * inv;
-    V3 t1 = v3(fminI_(tMin.x, tMax.x), fminI_(tMin.y, tMax.y), fminI_(tMin.z, tMax.z));
-    V3 t2 = v3(fmaxI_(tMin.x, tMax.x), fmaxI_(tMin.y, tMax.y), fmaxI_(tMin.z, tMax.z));
-    float nearD = fmax3_(t1.x, t1.y, t1.z);
-    float farD = fmin3_(t2.x, t2.y, t2.z);
-    // The reference returns early when nearD > t; as a select it is the same value without a branch.
-    return (!(nearD > t) && farD >= nearD && farD > 0.0f) ? nearD : 1e20f;
-}
-
-// Byte k of a word as float (v_cvt_f32_ubyteK).
-template <int K> __device__ __forceinline__ float byteAsFloat(uint32_t w) { return (float)((w >> (8 * K)) & 0xffu); }
-
-// Entry distance of child K of a four-wide node, 1e20 when the ray misses it or enters it
-// beyond `t`.  nx..fz are the words holding the planes the ray meets first / last on each axis,
-// (sx, bx) map a plane number q to the ray parameter q*sx + bx.
-typedef float float2v __attribute__((ext_vector_type(2)));
-template <int K>
-__device__ __forceinline__ float wideChildDistance(uint32_t nx, uint32_t ny, uint32_t nz, uint32_t fx, uint32_t fy, uint32_t fz,
-                                                   float2v sx, float2v sy, float2v sz, float2v bx, float2v by, float2v bz, float t) {
-    // (near, far) of one axis as one packed multiply-add
-    const float2v tx = __builtin_elementwise_fma((float2v){byteAsFloat<K>(nx), byteAsFloat<K>(fx)}, sx, bx);
-    const float2v ty = __builtin_elementwise_fma((float2v){byteAsFloat<K>(ny), byteAsFloat<K>(fy)}, sy, by);
-    const float2v tz = __builtin_elementwise_fma((float2v){byteAsFloat<K>(nz), byteAsFloat<K>(fz)}, sz, bz);
-    const float nearD = fmax3_(tx.x, ty.x, tz.x);
-    const float farD = fmin3_(tx.y, ty.y, tz.y);
-    return (nearD <= t && farD >= nearD && farD > 0.0f) ? nearD : 1e20f;
-}
-
-// Orders two (distance, reference) pairs by distance.
-__device__ __forceinline__ void orderPair(float &da, int32_t &ca, float &db, int32_t &cb) {
-    const bool swap = db < da;
-    const float dLo = swap ? db : da, dHi = swap ? da : db;
-    const int32_t cLo = swap ? cb : ca, cHi = swap ? ca : cb;
-    da = dLo; db = dHi; ca = cLo; cb = cHi;
-}
-
-// Alpha-cut rejection inside hitTriangle (src/RayScene.cpp:547-577).  Only
-// triangles flagged kTriAlphaTest at commit time come here.  The traversal kernel
-// runs it in a phase of its own, where no node or triangle temporaries are live.
-__device__ __forceinline__ bool alphaCutRejects(const SceneView &sc, const PackedTri &pt, V3 ro, V3 rd, float t) {
-    const ModelDesc &md = sc.modelDesc[pt.model & kTriModelMask];
-    const float *idw = sc.models + md.identBase + pt.ident * kIdentWords;
-    int32_t idx[3] = {f2i(idw[0]), f2i(idw[1]), f2i(idw[2])};
-    TriVerts tv;
-    loadTriVerts(sc, md.vertBase, idx, tv);
-    const float *m = sc.materials + pt.material * kMaterialWords;
-    int baseColor = f2i(m[1]);
-    float alphaCut = m[20];
-    V2 uv = cramerUV(tv.p[0], tv.p[1], tv.p[2], tv.uv[0], tv.uv[1], tv.uv[2], ro + t * rd);
-    int at = texelOffset(sc, baseColor, uv);
-    return sc.textures[at + 3] < alphaCut;
-}
-
-// Pins loaded values at this point of the program, so that the compiler cannot sink one of the
-// loads below a later branch (which turns one round trip to memory into two dependent ones).
-__device__ __forceinline__ void pinLoaded(const float4 &a, const float4 &b, const float4 &c) {
-    asm volatile("" : : "v"(a.x), "v"(a.w), "v"(b.x), "v"(b.w), "v"(c.x), "v"(c.w));
-}
-
-// The same for whole 16-byte values: each must sit in four consecutive registers here, which keeps
-// the compiler from re-cutting the record into loads that straddle the 16-byte pieces.
-typedef float float4v __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void pinLoaded(float4v &a, float4v &b, float4v &c) { asm volatile("" : "+v"(a), "+v"(b), "+v"(c)); }
-__device__ __forceinline__ float4 asFloat4(const float4v &v) { return make_float4(v.x, v.y, v.z, v.w); }
-
-// Per-lane traversal state of the refilling variant.
-struct LaneRay {
-    V3 ro, rd, inv;
-    float closest, afterPrimitives, tModel, maxT;
-    float tStop;   // any accepted hit closer than this ends the ray at once (occluded shadow ray)
-    float bestU, bestV, mU, mV;
-    uint32_t bestId, mBest, slot;
-    int32_t ref, model, sp;
-    // Alpha-cut variant only: a candidate hit on an alpha-tested triangle waits here for the
-    // texture lookup (pendTri != kMiss), and `resume` is where the leaf loop continues afterwards.
-    // (Recomputing t,u,v in the lookup phase and folding `resume` into the leaf reference saves
-    // four registers here but makes the compiler spill inside the main loop: measured slower.)
-    float pendT, pendU, pendV;
-    uint32_t pendTri, resume;
-};
-
-// Root references of the first models, copied to LDS by the traversal kernel: entering a model
-// then costs an LDS read instead of a round trip to memory on every ray's critical path.
-constexpr int kRootCache = 64;
-constexpr int32_t kNoRoot = (int32_t)0x80000000;   // model without nodes; not a valid child reference
-
-__device__ __forceinline__ bool enterModel(const SceneView &sc, const int32_t *rootLds, LaneRay &r, int m) {
-    for (; m < sc.modelsCount; ++m) {
-        int32_t root;
-        if (rootLds != nullptr && m < kRootCache) {
-            root = rootLds[m];
-        } else {
-            const ModelDesc &md = sc.modelDesc[m];
-            root = md.nodesCount > 0 ? md.rootRef : kNoRoot;
-        }
-        if (root == kNoRoot) continue;
-        r.model = m;
-        r.ref = root;
-        r.sp = 0;
-        r.tModel = 1e20f;
-        r.maxT = r.closest;
-        r.mBest = kMiss;
-        r.mU = 0.0f;
-        r.mV = 0.0f;
-        r.pendTri = kMiss;
-        r.resume = 0u;
-        return true;
-    }
-    return false;
-}
-
-// Analytic primitives, linear scan (hit(), src/RayScene.cpp:855-891); leaves the
-// closest primitive hit in the lane state.
-template <bool COUNT>
-__device__ __forceinline__ void intersectPrimitives(const SceneView &sc, LaneRay &r, uint32_t &cntTris) {
-    const V3 ro = r.ro, rd = r.rd;
-    float closest = 1e20f;
-    uint32_t bestId = kMiss;
-    float bestU = 0.0f, bestV = 0.0f;
-    int at = 0;
-    for (int pi = 0; pi < sc.objectCount; ++pi) {
-        const int type = ldi(sc.objects, at);
-        at += 2;
-        if (type == 0) {            // hitSphere, src/RayScene.cpp:441-466
-            V3 center = ld3(sc.objects, at);
-            float radius = ldw(sc.objects, at + 3);
-            at += 4;
-            V3 dir = center - ro;
-            float a = dot(rd, rd);
-            float h = dot(rd, dir);
-            float c = dot(dir, dir) - radius * radius;
-            float disc = h * h - a * c;
-            if (!(disc < 0.0f)) {
-                float sq = sqrt_(disc);
-                float t = (h - sq) / a;
-                bool ok = true;
-                if (t <= 1e-8f || t >= closest) {
-                    t = (h + sq) / a;
-                    if (t <= 1e-8f || t >= closest) ok = false;
-                }
-                if (ok) { closest = t; bestId = kPrimBit | (uint32_t)pi; bestU = 0.0f; bestV = 0.0f; }
-            }
-        } else if (type == 1) {     // hitQuad, src/RayScene.cpp:478-508 (+ cull, :870)
-            V3 qq = ld3(sc.objects, at), qu = ld3(sc.objects, at + 3), qv = ld3(sc.objects, at + 6);
-            bool cull = ldw(sc.objects, at + 9) != 0.0f;
-            at += 10;
-            V3 normal = cross(qu, qv);
-            if (!(cull && dot(rd, normal) > 0.0f)) {
-                float denom = dot(normal, rd);
-                float nn = dot(normal, normal);
-                if (!(abs_(denom) < kMinDenominator)) {
-                    float t = dot(normal, qq - ro) / denom;
-                    if (!(t < 1e-8f || t > closest || t >= closest)) {
-                        V3 rel = (ro + t * rd) - qq;
-                        float alpha = dot(normal, cross(rel, qv)) / nn;
-                        float beta = dot(normal, cross(qu, rel)) / nn;
-                        if (!(alpha < 0.0f || alpha > 1.0f || beta < 0.0f || beta > 1.0f)) {
-                            closest = t; bestId = kPrimBit | (uint32_t)pi; bestU = 0.0f; bestV = 0.0f;
-                        }
-                    }
-                }
-            }
-        } else if (type == 2) {     // top-level Triangle through hitTriangle
-            V3 A = ld3(sc.objects, at), B = ld3(sc.objects, at + 3), C = ld3(sc.objects, at + 6);
-            at += 18;
-            if (COUNT) cntTris++;
-            V3 ab = B - A, ac = C - A;
-            V3 nrm = cross(ab, ac);
-            float det = -dot(rd, nrm);
-            if (!(abs_(det) < 1e-8f)) {
-                V3 ao = ro - A;
-                V3 dao = cross(ao, rd);
-                float invDet = 1.0f / det;
-                float t = dot(ao, nrm) * invDet;
-                if (!(t < 0.0f || t > closest || t >= closest)) {
-                    float u = dot(ac, dao) * invDet;
-                    float v = -dot(ab, dao) * invDet;
-                    if (!(u < 0.0f || v < 0.0f || u + v > 1.0f)) {
-                        closest = t; bestId = kPrimBit | (uint32_t)pi; bestU = u; bestV = v;
-                    }
-                }
-            }
-        }
-    }
-    r.closest = closest;
-    r.afterPrimitives = closest;
-    r.bestId = bestId;
-    r.bestU = bestU;
-    r.bestV = bestV;
-}
-
-// Persistent traversal kernel: a wave keeps up to 64 rays in flight
-// and, whenever `refillLanes` or more lanes are idle, reserves that many queue
-// entries with one atomic and hands them to the idle lanes (refillLanes = 64
-// keeps whole 64-ray packets together, which is what coherent camera rays want;
-// incoherent rays run best around 32).  The traversal stack of each lane lives
-// in LDS ([entry][lane], conflict free).
-//
-// WIDE variants walk the models' four-wide trees instead: half as many dependent node loads per
-// ray.  They find the same closest hit (the later model winning a tie between models, as in the
-// reference), but not by the reference's visiting order, so between two triangles of one model at
-// the same distance the other one may win.  (One tree over all models was tried: fewer nodes per
-// ray but slower, because lanes then mix the small models' leaves with the large model's inner
-// nodes and the two phases of the loop run emptier.)
-template <bool COUNT, int STACK, bool ALPHA, bool PRIMS, bool ROOTS, bool WIDE>
-__global__ __launch_bounds__(kBlock, WIDE ? (ALPHA ? RT_WWIDE_ALPHA : RT_WWIDE)
-                                          : (STACK <= 20 ? (ALPHA ? RT_WALPHA : PRIMS ? 7 : RT_W20) : STACK <= 24 ? (ALPHA ? (RT_WALPHA < 6 ? RT_WALPHA : 6) : 6) : 5)) void k_trace(SceneView sc, PathBuffers pb, int extParity, int stage, int refillLanes, int innerShare) {
-    __shared__ int32_t stackLds[kBlock / 64][STACK][64];
-    // ROOTS variants (scenes with more than two models): the models' root references sit in LDS.
-    // With one or two models the descriptor loads hit the L1 and the plain variant is faster
-    // (the table costs registers: -3 %); with six models the table gives +10 %.
-    __shared__ int32_t rootTable[ROOTS ? kRootCache : 1];
-    const uint32_t lane = laneId();
-    int32_t(*stack)[64] = stackLds[threadIdx.x >> 6];
-    const int32_t *rootLds = ROOTS ? rootTable : nullptr;
-    if (ROOTS && (int)threadIdx.x < kRootCache) {
-        int32_t root = kNoRoot;
-        if ((int)threadIdx.x < sc.modelsCount) {
-            const ModelDesc &md = sc.modelDesc[threadIdx.x];
-            if (md.nodesCount > 0) root = md.rootRef;
-        }
-        rootTable[threadIdx.x] = root;
-    }
-    if (ROOTS) __syncthreads();
-
-    Stage *st = &pb.stages[stage];
-    const uint32_t *qExt = extParity >= 0 ? pb.qExt[extParity] : nullptr;
-    const int firstSource = qExt ? 0 : kSubQueues;
-    const int numSources = 2 * kSubQueues - firstSource;
-    const uint32_t waveId = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-    int source = firstSource + (int)(waveId % (uint32_t)numSources);
-    bool drained = false;    // every source has been seen empty
-
-    uint32_t cntNodes = 0, cntTris = 0, maxSp = 0;
-    bool active = false;
-    LaneRay r;
-    r.slot = 0;
-    // Four-wide variants: this lane's column of the stack part that does not fit in LDS.
-    int32_t *overflow = WIDE ? pb.overflow + (size_t)waveId * pb.overflowDepth * 64 + lane : nullptr;
-    // The four-wide variants run at the edge of their register budget: the lane's column of the LDS
-    // stack is addressed from the lane number re-read on the spot (two instructions) rather than from
-    // a value kept for the whole kernel, which the compiler would keep in scratch memory and reload
-    // at every push.
-    int32_t *const waveStack = &stackLds[0][0][0] + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * (STACK * 64);
-    auto stackSlot = [&](int32_t sp) -> int32_t * { return WIDE ? waveStack + sp * 64 + laneIdNow() : &stack[sp][lane]; };
-    auto pushWide = [&](int32_t ref) {
-        if (r.sp < STACK) *stackSlot(r.sp) = ref;
-        else overflow[(size_t)(r.sp - STACK) * 64] = ref;
-        r.sp++;
-    };
-    // Opens a four-wide node: the nearest child the ray enters becomes the lane's next reference,
-    // the others go on the stack with the farthest at the bottom.  True when no child is entered.
-    // Children are culled with maxT, the closest hit of this AND the earlier models (a triangle at
-    // exactly that distance still replaces it, so boxes entered at maxT stay in); the reference
-    // culls with the current model's hit only and walks every model's tree from the top.
-    auto openWideNode = [&](const float4 &n0, const float4 &n1, const float4 &n2, const float4 &n3) -> bool {
-        if (COUNT) cntNodes++;
-        const float sx1 = n1.x * r.inv.x, sy1 = n1.y * r.inv.y, sz1 = n1.z * r.inv.z;
-        const float bx1 = (n0.x - r.ro.x) * r.inv.x, by1 = (n0.y - r.ro.y) * r.inv.y, bz1 = (n0.z - r.ro.z) * r.inv.z;
-        const float2v sx = {sx1, sx1}, sy = {sy1, sy1}, sz = {sz1, sz1}, bx = {bx1, bx1}, by = {by1, by1}, bz = {bz1, bz1};
-        const uint32_t lox = __float_as_uint(n2.x), loy = __float_as_uint(n2.y), loz = __float_as_uint(n2.z);
-        const uint32_t hix = __float_as_uint(n3.x), hiy = __float_as_uint(n3.y), hiz = __float_as_uint(n3.z);
-        const bool ngx = r.inv.x < 0.0f, ngy = r.inv.y < 0.0f, ngz = r.inv.z < 0.0f;
-        const uint32_t nx = ngx ? hix : lox, fx = ngx ? lox : hix;
-        const uint32_t ny = ngy ? hiy : loy, fy = ngy ? loy : hiy;
-        const uint32_t nz = ngz ? hiz : loz, fz = ngz ? loz : hiz;
-        float d0 = wideChildDistance<0>(nx, ny, nz, fx, fy, fz, sx, sy, sz, bx, by, bz, r.maxT);
-        float d1 = wideChildDistance<1>(nx, ny, nz, fx, fy, fz, sx, sy, sz, bx, by, bz, r.maxT);
-        float d2 = wideChildDistance<2>(nx, ny, nz, fx, fy, fz, sx, sy, sz, bx, by, bz, r.maxT);
-        float d3 = wideChildDistance<3>(nx, ny, nz, fx, fy, fz, sx, sy, sz, bx, by, bz, r.maxT);
-        int32_t c0 = __float_as_int(n0.w), c1 = __float_as_int(n1.w), c2 = __float_as_int(n2.w), c3 = __float_as_int(n3.w);
-        orderPair(d0, c0, d1, c1);
-        orderPair(d2, c2, d3, c3);
-        orderPair(d0, c0, d2, c2);
-        orderPair(d1, c1, d3, c3);
-        orderPair(d1, c1, d2, c2);
-        if (!(d0 < 1e20f)) return true;
-        if (d3 < 1e20f) { pushWide(c3); }
-        if (d2 < 1e20f) { pushWide(c2); }
-        if (d1 < 1e20f) { pushWide(c1); }
-        r.ref = c0;
-        return false;
-    };
-    // Möller–Trumbore as hitTriangle writes it (src/RayScene.cpp:510-545); returns true when the
-    // hit waits for its alpha-cut lookup.
-    auto testTriangle = [&](uint32_t ti, const float4 &q0, const float4 &q1, const float4 &q2) -> bool {
-        if (COUNT) cntTris++;
-        const V3 A = v3(q0.x, q0.y, q0.z), ab = v3(q1.x, q1.y, q1.z), ac = v3(q2.x, q2.y, q2.z);
-        const V3 nrm = cross(ab, ac);
-        const float det = -dot(r.rd, nrm);
-        if (abs_(det) < 1e-8f) return false;
-        const V3 ao = r.ro - A;
-        const V3 dao = cross(ao, r.rd);
-        const float invDet = 1.0f / det;
-        const float t = dot(ao, nrm) * invDet;
-        if (t < 0.0f || t > r.maxT) return false;
-        // A later model's triangle at exactly the closest distance so far replaces the hit, a
-        // triangle of the same model does not (src/RayScene.cpp:535, :405-406).  The four-wide walk
-        // keeps one distance for both tests: maxT is this model's hit once mBest is set.
-        if (WIDE ? (r.mBest != kMiss && t == r.maxT) : (t >= r.tModel)) return false;
-        const float u = dot(ac, dao) * invDet;
-        const float v = -dot(ab, dao) * invDet;
-        if (u < 0.0f || v < 0.0f || u + v > 1.0f) return false;
-        if (ALPHA && (__float_as_int(q1.w) & kTriAlphaTest)) {
-            r.pendT = t;
-            r.pendU = u;
-            r.pendV = v;
-            r.pendTri = ti;
-            return true;
-        }
-        if (!WIDE) r.tModel = t;   // the four-wide walk keeps its closest hit in maxT alone
-        r.maxT = t;
-        r.mBest = ti;
-        r.mU = u;
-        r.mV = v;
-        return false;
-    };
-
-    for (;;) {
-        if (COUNT && active) maxSp = max(maxSp, (uint32_t)r.sp);
-        const unsigned long long idleMask = __ballot(!active);
-        const int nIdle = __popcll(idleMask);
-        if (!drained && nIdle >= refillLanes) {
-            // `source` is the same in every lane; saying so keeps the queue header in scalar registers
-            // and turns the load of its length into a scalar load.
-            const int src = __builtin_amdgcn_readfirstlane(source);
-            SubQueue *sq = (src < kSubQueues) ? &st->ext[src] : &st->shadow[src - kSubQueues];
-            const uint32_t n = sq->count;
-            const int leader = __ffsll((long long)idleMask) - 1;
-            uint32_t base = n;
-            if (n != 0u) {
-                if ((int)lane == leader) base = atomicAdd(&sq->cursor, (uint32_t)nIdle);
-                base = __shfl(base, leader);
-            }
-            if (base >= n) {
-                bool has = false;
-                if ((int)lane >= firstSource && (int)lane < 2 * kSubQueues) {
-                    SubQueue *o = ((int)lane < kSubQueues) ? &st->ext[lane] : &st->shadow[lane - kSubQueues];
-                    has = __hip_atomic_load(&o->cursor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < o->count;
-                }
-                const unsigned long long live = __ballot(has);
-                if (live == 0ull) {
-                    drained = true;
-                } else {
-                    int pick = (int)(waveId % (uint32_t)__popcll(live));
-                    unsigned long long m = live;
-                    while (pick-- > 0) m &= m - 1ull;
-                    source = __ffsll((long long)m) - 1;
-                }
-                if (nIdle == 64) {
-                    if (drained) break;
-                    continue;
-                }
-            } else {
-                const uint32_t mine = base + (uint32_t)__popcll(idleMask & ((1ull << lane) - 1ull));
-                if (!active && mine < n) {
-                    const uint32_t *q = (src < kSubQueues) ? qExt + (size_t)src * pb.subCap
-                                                             : pb.qShadow + (size_t)(src - kSubQueues) * pb.subCap;
-                    r.slot = q[mine];
-                    const float4 *rp = reinterpret_cast<const float4 *>(&pb.rays[r.slot]);
-                    const float4 r0 = rp[0], r1 = rp[1];
-                    r.ro = v3(r0.x, r0.y, r0.z);
-                    r.rd = v3(r1.x, r1.y, r1.z);
-                    if (WIDE) {
-                        // Only box tests use inv here, and the boxes carry a margin: the one-instruction
-                        // reciprocal will do.  Plane numbers are scaled by inv, so keep it finite (a
-                        // direction component of zero then behaves like a very small one of the same sign).
-                        r.inv = v3(__builtin_amdgcn_rcpf(r.rd.x), __builtin_amdgcn_rcpf(r.rd.y), __builtin_amdgcn_rcpf(r.rd.z));
-                        r.inv = v3(fminI_(fmaxI_(r.inv.x, -1e18f), 1e18f), fminI_(fmaxI_(r.inv.y, -1e18f), 1e18f), fminI_(fmaxI_(r.inv.z, -1e18f), 1e18f));
-                    } else {
-                        r.inv = v3(1.0f / r.rd.x, 1.0f / r.rd.y, 1.0f / r.rd.z);
-                    }
-                    r.tStop = r1.w;
-                    if (PRIMS) {
-                        intersectPrimitives<COUNT>(sc, r, cntTris);
-                        active = !(r.closest < r.tStop) && enterModel(sc, rootLds, r, 0);
-                        if (!active) {   // no models (or already occluded): the primitive result is final
-                            HitRec rec;
-                            rec.t = r.closest; rec.u = r.bestU; rec.v = r.bestV; rec.id = r.bestId;
-                            *reinterpret_cast<float4 *>(&pb.hits[r.slot]) = *reinterpret_cast<const float4 *>(&rec);
-                        }
-                    } else {
-                        // Without analytic primitives the record starts as a miss and is
-                        // overwritten whenever a model ends with a closer hit, so the best
-                        // hit need not be carried in registers.
-                        r.closest = 1e20f;
-                        HitRec rec;
-                        rec.t = 1e20f; rec.u = 0.0f; rec.v = 0.0f; rec.id = kMiss;
-                        *reinterpret_cast<float4 *>(&pb.hits[r.slot]) = *reinterpret_cast<const float4 *>(&rec);
-                        active = enterModel(sc, rootLds, r, 0);
-                    }
-                }
-            }
-        } else if (nIdle == 64) {
-            break;
-        }
-
-        // One phase per iteration, chosen for the whole wave: open inner nodes while
-        // at least `innerShare`/64 of the active lanes sit on one, otherwise test the
-        // leaves the other lanes are parked on.  Lanes of the other kind wait, so each
-        // phase runs with most lanes enabled instead of both code paths every iteration.
-        const bool onInner = active && r.ref >= 0;
-        int nActive = 64 - __popcll(__ballot(!active));
-        const int nInner = __popcll(__ballot(onInner));
-        if (ALPHA) {
-            // Third phase: candidate hits on alpha-tested triangles wait until eight lanes have one
-            // (or nothing else is left to do) and are then resolved together; the texture lookup
-            // needs many registers, and here none of the node/triangle temporaries are live.
-            const bool pending = active && r.pendTri != kMiss;
-            const int nPending = __popcll(__ballot(pending));
-            if (nPending > 0 && (nPending >= 8 || nPending == nActive)) {
-                if (pending) {
-                    if (!alphaCutRejects(sc, sc.tris[r.pendTri], r.ro, r.rd, r.pendT)) {
-                        if (!WIDE) r.tModel = r.pendT;
-                        r.maxT = r.pendT;
-                        r.mBest = r.pendTri;
-                        r.mU = r.pendU;
-                        r.mV = r.pendV;
-                    }
-                    r.resume = r.pendTri - ((~(uint32_t)r.ref) >> 2) + 1u;
-                    r.pendTri = kMiss;
-                }
-                continue;
-            }
-            nActive -= nPending;
-        }
-        const bool innerPhase = nInner * 64 >= nActive * innerShare;
-        bool pop = false, occluded = false;
-        if (innerPhase) {
-            if (WIDE) {
-                if (onInner) {
-                    const float4 *np = reinterpret_cast<const float4 *>(&sc.wnodes[r.ref]);
-                    const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
-                    pop = openWideNode(n0, n1, n2, n3);
-                }
-            } else if (onInner) {
-                if (COUNT) cntNodes++;
-                const float4 *np = reinterpret_cast<const float4 *>(&sc.nodes[r.ref]);
-                const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
-                const int32_t left = __float_as_int(n0.w), right = __float_as_int(n1.w);
-                const float dL = slabDistance(v3(n0.x, n0.y, n0.z), v3(n1.x, n1.y, n1.z), r.ro, r.inv, r.tModel);
-                const float dR = slabDistance(v3(n2.x, n2.y, n2.z), v3(n3.x, n3.y, n3.z), r.ro, r.inv, r.tModel);
-                const bool pushL = dL < r.tModel, pushR = dR < r.tModel;
-                const bool leftFirst = dL < dR;
-                const bool takeNear = leftFirst ? pushL : pushR;
-                const bool takeFar = leftFirst ? pushR : pushL;
-                const int32_t nearRef = leftFirst ? left : right;
-                const int32_t farRef = leftFirst ? right : left;
-                pop = true;
-                if (takeNear) {
-                    if (takeFar && r.sp < STACK) stack[r.sp++][lane] = farRef;
-                    r.ref = nearRef;
-                    pop = false;
-                } else if (takeFar) {
-                    r.ref = farRef;
-                    pop = false;
-                }
-            }
-        } else if (active && r.ref < 0 && !(ALPHA && r.pendTri != kMiss)) {
-            const uint32_t code = ~(uint32_t)r.ref;
-            const uint32_t first = code >> 2, ntri = code & 3u;
-            bool parked = false;
-            if (WIDE && !ALPHA) {
-                // The usual leaf holds one or two triangles: fetch both in one round trip (the binary
-                // variants have no registers to spare for this: -10 % there, +2 % here).
-                const float4v *tp = reinterpret_cast<const float4v *>(&sc.tris[first]);
-                if (ntri > 0u) {
-                    const bool two = ntri > 1u;
-                    float4v a0 = tp[0], a1 = tp[1], a2 = tp[2];
-                    float4v b0 = a0, b1 = a1, b2 = a2;
-                    if (two) { b0 = tp[3]; b1 = tp[4]; b2 = tp[5]; }
-                    pinLoaded(a0, a1, a2);
-                    pinLoaded(b0, b1, b2);
-                    testTriangle(first, asFloat4(a0), asFloat4(a1), asFloat4(a2));
-                    if (two) testTriangle(first + 1u, asFloat4(b0), asFloat4(b1), asFloat4(b2));
-                    for (uint32_t k = 2u; k < ntri; ++k) {
-                        float4v q0 = tp[3 * k], q1 = tp[3 * k + 1], q2 = tp[3 * k + 2];
-                        pinLoaded(q0, q1, q2);
-                        testTriangle(first + k, asFloat4(q0), asFloat4(q1), asFloat4(q2));
-                    }
-                }
-            } else {
-                for (uint32_t k = ALPHA ? r.resume : 0u; k < ntri; ++k) {
-                    const uint32_t ti = first + k;
-                    const float4 *tp = reinterpret_cast<const float4 *>(&sc.tris[ti]);
-                    const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
-                    pinLoaded(q0, q1, q2);   // all three in one round trip, before the determinant test
-                    if (testTriangle(ti, q0, q1, q2)) {
-                        parked = true;
-                        break;
-                    }
-                }
-            }
-            if (!parked) {
-                if (ALPHA) r.resume = 0u;
-                pop = true;
-                occluded = WIDE ? (r.mBest != kMiss && r.maxT < r.tStop) : (r.tModel < r.tStop);
-            }
-        }
-        if (pop) {
-            if (r.sp > 0 && !occluded) {
-                --r.sp;
-                if (WIDE && r.sp >= STACK) r.ref = overflow[(size_t)(r.sp - STACK) * 64];
-                else r.ref = *stackSlot(r.sp);
-            } else {
-                if (r.mBest != kMiss) {
-                    const float tHit = WIDE ? r.maxT : r.tModel;
-                    r.closest = tHit;
-                    if (PRIMS) {
-                        r.bestId = r.mBest;
-                        r.bestU = r.mU;
-                        r.bestV = r.mV;
-                    } else {
-                        HitRec rec;
-                        rec.t = tHit; rec.u = r.mU; rec.v = r.mV; rec.id = r.mBest;
-                        *reinterpret_cast<float4 *>(&pb.hits[r.slot]) = *reinterpret_cast<const float4 *>(&rec);
-                    }
-                }
-                if (occluded || !enterModel(sc, rootLds, r, r.model + 1)) {
-                    if (PRIMS) {
-                        uint32_t id = r.bestId;
-                        if (id != kMiss && (id & kPrimBit) == 0u && !(r.afterPrimitives > r.closest)) id |= kNoTexBit;
-                        HitRec rec;
-                        rec.t = r.closest; rec.u = r.bestU; rec.v = r.bestV; rec.id = id;
-                        *reinterpret_cast<float4 *>(&pb.hits[r.slot]) = *reinterpret_cast<const float4 *>(&rec);
-                    }
-                    active = false;
-                }
-            }
-        }
-    }
-
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        unsigned long long total = 0;
-        for (int q = 0; q < kSubQueues; ++q) total += (qExt ? st->ext[q].count : 0u) + st->shadow[q].count;
-        atomicAdd(&pb.counters[0], total);
-    }
-    if (COUNT) {
-        for (int off = 32; off > 0; off >>= 1) {
-            cntNodes += __shfl_down(cntNodes, off);
-            cntTris += __shfl_down(cntTris, off);
-            maxSp = max(maxSp, (uint32_t)__shfl_down(maxSp, off));
-        }
-        if (lane == 0) {
-            atomicAdd(&pb.counters[1], (unsigned long long)cntNodes);
-            atomicAdd(&pb.counters[2], (unsigned long long)cntTris);
-            atomicMax(&pb.counters[4], (unsigned long long)maxSp);
-        }
-    }
-}
-
-// ---- shading ---------------------------------------------------------------------------
-// Adds the per-lane counts with one atomic per wave.  All lanes must call it.
-__device__ __forceinline__ void addShadedHits(const PathBuffers &pb, uint32_t shaded) {
-    for (int off = 32; off > 0; off >>= 1) shaded += __shfl_down(shaded, off);
-    if (laneId() == 0 && shaded) atomicAdd(&pb.counters[3], (unsigned long long)shaded);
-}
-
-struct ShadowHit {
-    V3 normal;       // s_info.normal (unflipped)
-    bool frontFace;
-    float t;
-    V3 emissionColor;
-    float emissionStrength;
-};
-
-// State of the shadow ray's closest hit.  A miss leaves the zero-initialised
-// HitInfo with the default material 0 (the pinned reading of the
-// uninitialised `s_info`, src/RayTracer.cpp:435-439).
-__device__ __forceinline__ ShadowHit shadowHitOf(const SceneView &sc, const RayRec &sr, const HitRec &h, unsigned long long *counters) {
-    ShadowHit s;
-    if (h.id == kMiss) {
-        MaterialD m0 = loadMaterial(sc, 0);
-        s.normal = v3s(0.0f);
-        s.frontFace = false;
-        s.t = 1e20f;
-        s.emissionColor = m0.emissionColor;
-        s.emissionStrength = m0.emissionStrength;
-    } else {
-        HitInfoD info = resolveHit(sc, v3(sr.ox, sr.oy, sr.oz), v3(sr.dx, sr.dy, sr.dz), h);
-        s.normal = info.normal;
-        s.frontFace = info.front_face;
-        s.t = info.t;
-        s.emissionColor = info.mat.emissionColor;
-        s.emissionStrength = info.mat.emissionStrength;
-    }
-    (void)counters;
-    return s;
-}
-
-// NEE connection (src/RayTracer.cpp:439-477 RGB, :1162-1200 Spectral) for the
-// shadow rays traced in `stage`; adds into the owning path's radiance.
-template <bool SPECTRAL>
-__global__ __launch_bounds__(kBlock) void k_connect(SceneView sc, Batch bt, PathBuffers pb, int stage, int countOn, int skipOccluded) {
-    const uint32_t sub = blockIdx.x % kSubQueues;
-    const uint32_t n = pb.stages[stage].shadow[sub].count;
-    const uint32_t *qIn = pb.qShadow + (size_t)sub * pb.subCap;
-    const uint32_t stride = (gridDim.x / kSubQueues) * kBlock;
-    uint32_t shaded = 0;
-    for (uint32_t i = (blockIdx.x / kSubQueues) * kBlock + threadIdx.x; i < n; i += stride) {
-        const uint32_t slot = qIn[i];
-        const uint32_t path = slot - bt.P;
-        const RayRec sr = pb.rays[slot];
-        const HitRec h = pb.hits[slot];
-        const float4 a = pb.neeA[path], b = pb.neeB[path], c = pb.neeC[path];
-        // RGB: a hit nearer than distToLight - 1e-4 contributes nothing; skip its material.
-        if (!SPECTRAL && skipOccluded && !(h.t >= c.z - 1e-4f)) continue;
-        const ShadowHit s = shadowHitOf(sc, sr, h, pb.counters);
-        if (h.id != kMiss) shaded++;
-        const V3 sd = v3(sr.dx, sr.dy, sr.dz);
-        if (!SPECTRAL) {
-            const V3 brdfDirect = v3(a.x, a.y, a.z);
-            const float cosTheta = a.w;
-            const V3 rayColor = v3(b.x, b.y, b.z);
-            const float pdfArea = b.w, dist2 = c.x, pdfBrdfLd = c.y, distToLight = c.z;
-            if (s.emissionStrength > 0.0f && s.t >= distToLight - 1e-4f) {
-                V3 nl = s.normal;
-                if (!s.frontFace) nl = -nl;
-                nl = normalize(nl);
-                float cosThetaL = fmax_(dot(-sd, nl), 0.0f);
-                float G = cosThetaL / dist2;
-                float pdfNee = pdfArea / fmax_(G, kMinDenominator);
-                float wNee = (pdfNee * pdfNee) / fmax_(pdfNee * pdfNee + pdfBrdfLd * pdfBrdfLd, kMinDenominator);
-                V3 direct = brdfDirect * s.emissionColor * s.emissionStrength * cosTheta * G / pdfArea;
-                float4 sb = pb.stB[path];
-                V3 L = v3(sb.x, sb.y, sb.z) + rayColor * direct * wNee;
-                pb.stB[path] = make_float4(L.x, L.y, L.z, sb.w);
-            }
-        } else {
-            const float brdfDirect = a.x, cosTheta = a.y, pdf = a.z, dist2 = a.w;
-            const float pdfBrdfLd = b.x, distToLight = b.y, throughput = b.z, lambda = b.w;
-            if (s.emissionStrength > 0.0f && s.t <= distToLight + 0.01f) {
-                float cosThetaL = abs_(dot(-sd, normalize(s.normal)));
-                float G = cosThetaL / dist2;
-                float pdfNee = pdf / fmax_(G, kMinDenominator);
-                float wNee = (pdfNee * pdfNee) / fmax_(pdfNee * pdfNee + pdfBrdfLd * pdfBrdfLd, kMinDenominator);
-                float energy = reflectanceAt(lambda, s.emissionColor);
-                float direct = brdfDirect * energy * s.emissionStrength * cosTheta * G / pdf;
-                float4 sb = pb.stB[path];
-                sb.x = sb.x + throughput * direct * wNee;
-                pb.stB[path] = sb;
-            }
-        }
-        (void)c;
-    }
-    if (countOn) addShadedHits(pb, shaded);
-}
-
-// One bounce of traceColor (src/RayTracer.cpp:333-538) for every path in the stage's queue.
-#ifndef RT_SHADE_BLOCKS
-#define RT_SHADE_BLOCKS 4
-#endif
-__global__ __launch_bounds__(kBlock, RT_SHADE_BLOCKS) void k_shade_rgb(SceneView sc, FrameParams fp, Batch bt, PathBuffers pb, int stage, int countOn) {
-    const uint32_t sub = blockIdx.x % kSubQueues;
-    const uint32_t n = pb.stages[stage].ext[sub].count;
-    const uint32_t *qIn = pb.qExt[stage & 1] + (size_t)sub * pb.subCap;
-    uint32_t *qOut = pb.qExt[(stage + 1) & 1] + (size_t)sub * pb.subCap;
-    uint32_t *qShadowOut = pb.qShadow + (size_t)sub * pb.subCap;
-    Stage *next = &pb.stages[stage + 1];
-    const bool lastBounce = stage >= fp.bounces;
-    const uint32_t stride = (gridDim.x / kSubQueues) * kBlock;
-    uint32_t shaded = 0;
-
-    for (uint32_t base = (blockIdx.x / kSubQueues) * kBlock + (threadIdx.x & ~63u); base < n; base += stride) {
-        const uint32_t i = base + laneId();
-        bool wantShadow = false, wantExt = false;
-        uint32_t path = 0;
-        if (i < n) {
-            path = qIn[i];
-            const RayRec ray = pb.rays[path];
-            const HitRec h = pb.hits[path];
-            const float4 sA = pb.stA[path];
-            float4 sB = pb.stB[path];
-            V3 rayColor = v3(sA.x, sA.y, sA.z);
-            float prevBrdfPdf = sA.w;
-            V3 incoming = v3(sB.x, sB.y, sB.z);
-            uint32_t seed = __float_as_uint(sB.w);
-            const V3 ro = v3(ray.ox, ray.oy, ray.oz), rd = v3(ray.dx, ray.dy, ray.dz);
-
-            if (h.id == kMiss) {                                    // sky, :338-344
-                float t = rd.y * 0.5f + 0.5f;
-                V3 env = (1.0f - t) * v3s(1.0f) + t * fp.sky;
-                if (dot(fp.sky, fp.sky) > 0.0f) incoming = incoming + env * rayColor;
-                pb.stB[path] = make_float4(incoming.x, incoming.y, incoming.z, sB.w);
-            } else {
-                shaded++;
-                HitInfoD info = resolveHit(sc, ro, rd, h);
-                V3 N = normalize(info.normal);
-                const V3 V = normalize(-rd);
-                if (!info.front_face) N = -N;
-                const MaterialD &mat = info.mat;
-
-                if (dot(mat.emissionColor, mat.emissionColor) > 0.0f && mat.emissionStrength > 0.0f) {   // :356-378
-                    if (stage == 0 || !fp.nee) {   // without NEE every emitter hit counts in full (:374-376, :1089-1091)
-                        incoming = incoming + rayColor * mat.emissionColor * mat.emissionStrength;
-                    } else {
-                        float wBrdf;
-                        if (info.isPrimitive) {
-                            wBrdf = 1.0f;   // analytic emitters are never light-sampled
-                        } else {
-                            float pdfArea = 1.0f / info.area / (float)sc.lightSourcesCount / (float)info.modelLightCounts;
-                            float cosTheta = fmax_(dot(V, N), 0.0f);
-                            float pdfNee = pdfArea * (info.t * info.t) / fmax_(cosTheta, kMinDenominator);
-                            wBrdf = (prevBrdfPdf * prevBrdfPdf) / fmax_(prevBrdfPdf * prevBrdfPdf + pdfNee * pdfNee, kMinDenominator);
-                        }
-                        incoming = incoming + rayColor * wBrdf * mat.emissionColor * mat.emissionStrength;
-                    }
-                    pb.stB[path] = make_float4(incoming.x, incoming.y, incoming.z, sB.w);
-                } else {
-                    SurfaceRGB surf = surfaceOf(mat);
-                    surf.roughness = fmax_(surf.roughness, 0.0005f);
-                    const LobeProbs lp = lobeProbabilities(mat);
-
-                    V3 L;
-                    const float Xi = rand_float(seed);
-                    float diff = 0.0f, spec = 0.0f, sss = 0.0f;
-                    bool trans = false;
-                    if (Xi < lp.diffuse) {
-                        L = sampleCosineHemisphere(N, seed);
-                        diff = 1.0f;
-                    } else if (Xi < lp.diffuse + lp.specular) {
-                        L = sampleSpecular<false>(N, V, surf.roughness, seed);
-                        spec = 1.0f;
-                    } else if (Xi < lp.diffuse + lp.specular + lp.transmission) {
-                        L = sampleTransmission<false>(N, V, info.front_face, mat.ior, surf.roughness, seed);
-                        trans = true;
-                    } else {
-                        L = sampleCosineHemisphere(N, seed);
-                        sss = 1.0f;
-                    }
-                    L = normalize(L);
-
-                    const V3 H = normalize(V + L);
-                    const float NoV = clamp_(dot(N, V), 0.0f, 1.0f);
-                    const float NoL = clamp_(dot(N, L), 0.0f, 1.0f);
-                    const float NoH = clamp_(dot(N, H), 0.0f, 1.0f);
-                    const float VoH = clamp_(dot(V, H), 0.0f, 1.0f);
-                    const float LoV = clamp_(dot(L, V), 0.0f, 1.0f);
-
-                    if (!trans && fp.nee) {                         // NEE set-up, :421-437 (compiled out with ENABLE_NEE 0)
-                        float area, lightTriangleCount;
-                        V3 p = sampleLightPoint(sc, seed, area, lightTriangleCount);
-                        if (area > 0.0f) {
-                            V3 so = info.point + N * 0.001f;
-                            V3 toLight = p - so;
-                            float distToLight = length(toLight);
-                            V3 sdir = toLight / distToLight;
-                            float cosTheta = dot(N, sdir);
-                            if (cosTheta > 0.0f) {
-                                V3 Hd = normalize(V + sdir);
-                                float NoLd = clamp_(dot(N, sdir), 0.0f, 1.0f);
-                                float NoHd = clamp_(dot(N, Hd), 0.0f, 1.0f);
-                                float VoHd = clamp_(dot(V, Hd), 0.0f, 1.0f);
-                                float LoVd = clamp_(dot(sdir, V), 0.0f, 1.0f);
-                                float pdfArea = 1.0f / area / (float)sc.lightSourcesCount / lightTriangleCount;
-                                float pdfBrdfLd = lp.diffuse * (NoLd * kInvPi) + lp.specular * specularPdfRGB(NoHd, NoV, surf.roughness) +
-                                                  lp.subsurface * (NoLd * kInvPi);
-                                V3 brdfDirect = lp.diffuse * evalDiffuseRGB(surf, NoLd, NoV, VoHd) +
-                                                lp.specular * evalSpecularRGB(surf, NoV, NoLd, NoHd, VoHd) +
-                                                lp.subsurface * evalSubsurfaceRGB(surf, NoLd, NoV, LoVd);
-                                RayRec sr;
-                                sr.ox = so.x; sr.oy = so.y; sr.oz = so.z; sr.pad0 = 0.0f;
-                                // A hit nearer than distToLight - 1e-4 fails the visibility test
-                                // (s_info.t >= distToLight - 1e-4) whatever lies behind it, so the
-                                // traversal may stop at the first such hit without changing the result.
-                                sr.dx = sdir.x; sr.dy = sdir.y; sr.dz = sdir.z; sr.pad1 = fp.shadowEarlyOut ? distToLight - 1e-4f : kNeverStop;
-                                pb.rays[bt.P + path] = sr;
-                                pb.neeA[path] = make_float4(brdfDirect.x, brdfDirect.y, brdfDirect.z, cosTheta);
-                                pb.neeB[path] = make_float4(rayColor.x, rayColor.y, rayColor.z, pdfArea);
-                                pb.neeC[path] = make_float4(dot(toLight, toLight), pdfBrdfLd, distToLight, 0.0f);
-                                wantShadow = true;
-                            }
-                        }
-                    }
-
-                    V3 no = info.point + N * 0.001f;                // continue path, :484-537
-                    bool alive = true;
-                    if (trans) {
-                        no = info.point + L * 0.001f;
-                        if (!info.front_face) {
-                            V3 al = vmax(mat.albedo, v3s(kMinDenominator));
-                            V3 tr = v3(exp_(info.t * log_(al.x)), exp_(info.t * log_(al.y)), exp_(info.t * log_(al.z)));
-                            rayColor = rayColor * tr;
-                        }
-                        prevBrdfPdf = 1.0f;
-                    } else if (NoL < kMinDenominator) {
-                        alive = false;
-                    } else {
-                        V3 brdfSss = evalSubsurfaceRGB(surf, NoL, NoV, LoV);
-                        V3 brdfSpec = evalSpecularRGB(surf, NoV, NoL, NoH, VoH);
-                        V3 brdfDiff = evalDiffuseRGB(surf, NoL, NoV, VoH);
-                        float pSurf = 1.0f - lp.transmission;
-                        pSurf = (pSurf < 1e-8f) ? 0.0f : pSurf;
-                        float norm = (pSurf > 0.0f) ? 1.0f / pSurf : 1.0f;
-                        float pdfDiffRaw = (NoL * kInvPi) * norm;
-                        float pdfSpecRaw = specularPdfRGB(NoH, NoV, surf.roughness) * norm;
-                        float pdfSssRaw = NoL * kInvPi * norm;
-                        float pdfUsed = pdfDiffRaw * lp.diffuse * diff + pdfSpecRaw * lp.specular * spec + pdfSssRaw * lp.subsurface * sss;
-                        prevBrdfPdf = pdfDiffRaw * lp.diffuse + pdfSpecRaw * lp.specular + pdfSssRaw * lp.subsurface;
-                        V3 brdfTotal = (brdfSpec * spec + brdfDiff * diff + brdfSss * sss);
-                        V3 contribution = (brdfTotal * NoL) / fmax_(pdfUsed, kMinDenominator);
-                        rayColor = rayColor * contribution;
-                        float rr = fmin_(fmax_(rayColor.x, fmax_(rayColor.y, rayColor.z)), 0.95f);
-                        if (rand_float(seed) > rr) alive = false;
-                        else rayColor = rayColor / rr;
-                    }
-
-                    if (alive && !lastBounce) {
-                        RayRec nr;
-                        nr.ox = no.x; nr.oy = no.y; nr.oz = no.z; nr.pad0 = 0.0f;
-                        nr.dx = L.x; nr.dy = L.y; nr.dz = L.z; nr.pad1 = kNeverStop;
-                        pb.rays[path] = nr;
-                        pb.stA[path] = make_float4(rayColor.x, rayColor.y, rayColor.z, prevBrdfPdf);
-                        pb.stB[path] = make_float4(incoming.x, incoming.y, incoming.z, __uint_as_float(seed));
-                        wantExt = true;
-                    }
-                }
-            }
-        }
-        wavePush(wantShadow, qShadowOut, &next->shadow[sub].count, bt.P + path);
-        wavePush(wantExt, qOut, &next->ext[sub].count, path);
-    }
-    if (countOn) addShadedHits(pb, shaded);
-}
-
-// One bounce of traceColorWavelength (src/RayTracer.cpp:1056-1252).
-__global__ __launch_bounds__(kBlock) void k_shade_spectral(SceneView sc, FrameParams fp, Batch bt, PathBuffers pb, int stage, int countOn) {
-    const uint32_t sub = blockIdx.x % kSubQueues;
-    const uint32_t n = pb.stages[stage].ext[sub].count;
-    const uint32_t *qIn = pb.qExt[stage & 1] + (size_t)sub * pb.subCap;
-    uint32_t *qOut = pb.qExt[(stage + 1) & 1] + (size_t)sub * pb.subCap;
-    uint32_t *qShadowOut = pb.qShadow + (size_t)sub * pb.subCap;
-    Stage *next = &pb.stages[stage + 1];
-    const bool lastBounce = stage >= fp.bounces;
-    const uint32_t stride = (gridDim.x / kSubQueues) * kBlock;
-    uint32_t shaded = 0;
-
-    for (uint32_t base = (blockIdx.x / kSubQueues) * kBlock + (threadIdx.x & ~63u); base < n; base += stride) {
-        const uint32_t i = base + laneId();
-        bool wantShadow = false, wantExt = false;
-        uint32_t path = 0;
-        if (i < n) {
-            path = qIn[i];
-            const RayRec ray = pb.rays[path];
-            const HitRec h = pb.hits[path];
-            const float4 sA = pb.stA[path];
-            float4 sB = pb.stB[path];
-            float throughput = sA.x, prevBrdfPdf = sA.y;
-            const float lambda = sA.z;
-            float radiance = sB.x;
-            uint32_t seed = __float_as_uint(sB.w);
-            const V3 ro = v3(ray.ox, ray.oy, ray.oz), rd = v3(ray.dx, ray.dy, ray.dz);
-
-            if (h.id == kMiss) {                                    // :1061-1069
-                float t = rd.y * 0.5f + 0.5f;
-                V3 env = (1.0f - t) * v3s(1.0f) + t * fp.sky;
-                if (dot(fp.sky, fp.sky) > 0.0f) radiance += reflectanceAt(lambda, env) * throughput;
-                sB.x = radiance;
-                pb.stB[path] = sB;
-            } else {
-                shaded++;
-                HitInfoD info = resolveHit(sc, ro, rd, h);
-                V3 N = normalize(info.normal);
-                const V3 V = normalize(-rd);
-                MaterialD &mat = info.mat;
-
-                if (dot(mat.emissionColor, mat.emissionColor) > 0.0f && mat.emissionStrength > 0.0f) {   // :1075-1093
-                    float energy = reflectanceAt(lambda, mat.emissionColor);
-                    if (stage == 0 || !fp.nee) {   // without NEE every emitter hit counts in full (:374-376, :1089-1091)
-                        radiance += energy * throughput * mat.emissionStrength;
-                    } else {
-                        float wBrdf;
-                        if (info.isPrimitive) {
-                            wBrdf = 1.0f;
-                        } else {
-                            float pdfArea = fp.spectralPdfAsWritten ? 1.0f / info.area : 1.0f / info.area / (float)sc.lightSourcesCount / (float)info.modelLightCounts;
-                            float pdfNee = pdfArea * (info.t * info.t) / fmax_(abs_(dot(V, N)), kMinDenominator);
-                            wBrdf = (prevBrdfPdf * prevBrdfPdf) / fmax_(prevBrdfPdf * prevBrdfPdf + pdfNee * pdfNee, kMinDenominator);
-                        }
-                        radiance += energy * throughput * mat.emissionStrength * wBrdf;
-                    }
-                    sB.x = radiance;
-                    pb.stB[path] = sB;
-                } else {
-                    if (!info.front_face) N = -N;
-                    const float roughness = fmax_(mat.roughness, 0.001f);
-                    const LobeProbs lp = lobeProbabilities(mat);
-
-                    V3 L;
-                    const float Xi = rand_float(seed);
-                    float diff = 0.0f, spec = 0.0f, sss = 0.0f;
-                    bool trans = false;
-                    if (Xi < lp.diffuse) {
-                        L = sampleCosineHemisphere(N, seed);
-                        diff = 1.0f;
-                    } else if (Xi < lp.diffuse + lp.specular) {
-                        L = sampleSpecular<true>(N, V, roughness, seed);
-                        spec = 1.0f;
-                    } else if (Xi < lp.diffuse + lp.specular + lp.transmission) {
-                        // dispersion: ior + 0.03 * ((550/lambda)^2 - 1), :1122-1126
-                        float ior = mat.ior + 0.03f * (pow2_(550.0f / lambda) - 1.0f);
-                        L = sampleTransmission<true>(N, V, info.front_face, ior, roughness, seed);
-                        trans = true;
-                    } else {
-                        L = sampleCosineHemisphere(N, seed);
-                        sss = 1.0f;
-                    }
-                    L = normalize(L);
-
-                    const V3 H = normalize(V + L);
-                    const float NoV = clamp_(dot(N, V), 0.0f, 1.0f);
-                    const float NoL = clamp_(dot(N, L), 0.0f, 1.0f);
-                    const float NoH = clamp_(dot(N, H), 0.0f, 1.0f);
-                    const float VoH = clamp_(dot(V, H), 0.0f, 1.0f);
-                    const float LoV = clamp_(dot(L, V), 0.0f, 1.0f);
-
-                    SurfaceSpectral surf;
-                    surf.albedo = reflectanceAt(lambda, mat.albedo);
-                    surf.roughness = roughness;
-                    surf.metallic = mat.metallic;
-                    surf.specular = mat.specular;
-                    surf.specularTint = mat.specularTint;
-
-                    if (!trans && fp.nee) {                         // :1148-1160 (no cosTheta gate here; compiled out with ENABLE_NEE 0)
-                        float area, lightTriangleCount;
-                        V3 p = sampleLightPoint(sc, seed, area, lightTriangleCount);
-                        if (area > 0.0f) {
-                            V3 so = info.point + N * 0.001f;
-                            V3 toLight = p - so;
-                            V3 sdir = normalize(toLight);
-                            float distToLight = length(p - so);
-                            float cosTheta = fmax_(dot(N, sdir), 0.0f);
-                            float pdf = fp.spectralPdfAsWritten ? 1.0f / area : 1.0f / area / (float)sc.lightSourcesCount / lightTriangleCount;
-                            V3 Hd = normalize(V + sdir);
-                            float NoLd = clamp_(dot(N, sdir), 0.0f, 1.0f);
-                            float NoHd = clamp_(dot(N, Hd), 0.0f, 1.0f);
-                            float VoHd = clamp_(dot(V, Hd), 0.0f, 1.0f);
-                            float LoVd = clamp_(dot(sdir, V), 0.0f, 1.0f);
-                            float pSurf = 1.0f - lp.transmission;
-                            pSurf = (pSurf < 1e-8f) ? 0.0f : pSurf;
-                            float norm = (pSurf > 0.0f) ? 1.0f / pSurf : 1.0f;
-                            float pdfBrdfLd = lp.diffuse * (NoLd * kInvPi) + lp.specular * specularPdfSpectral(NoHd, VoHd, roughness) +
-                                              lp.subsurface * (NoLd * kInvPi);
-                            pdfBrdfLd *= norm;
-                            float brdfDirect = lp.diffuse * evalDiffuseSpectral(surf, NoLd, NoV, VoHd) +
-                                               lp.specular * evalSpecularSpectral(surf, NoV, NoLd, NoHd, VoHd) +
-                                               lp.subsurface * evalSubsurfaceSpectral(surf, NoLd, NoV, LoVd);
-                            RayRec sr;
-                            sr.ox = so.x; sr.oy = so.y; sr.oz = so.z; sr.pad0 = 0.0f;
-                            sr.dx = sdir.x; sr.dy = sdir.y; sr.dz = sdir.z; sr.pad1 = kNeverStop;
-                            pb.rays[bt.P + path] = sr;
-                            pb.neeA[path] = make_float4(brdfDirect, cosTheta, pdf, dot(toLight, toLight));
-                            pb.neeB[path] = make_float4(pdfBrdfLd, distToLight, throughput, lambda);
-                            wantShadow = true;
-                        }
-                    }
-
-                    const V3 no = info.point + L * 0.001f;          // :1205
-                    bool alive = true;
-                    if (trans) {
-                        if (!info.front_face) {
-                            float al = fmax_(surf.albedo, kMinDenominator);
-                            float absorption = -log_(al);
-                            throughput *= exp_(-absorption * info.t);
-                        }
-                        prevBrdfPdf = 1.0f;
-                    } else if (NoL < kMinDenominator) {
-                        alive = false;
-                    } else {
-                        float brdfSpec = evalSpecularSpectral(surf, NoV, NoL, NoH, VoH);
-                        float brdfDiff = evalDiffuseSpectral(surf, NoL, NoV, VoH);
-                        float brdfSss = evalSubsurfaceSpectral(surf, NoL, NoV, LoV);
-                        float pSurf = 1.0f - lp.transmission;
-                        pSurf = (pSurf < 1e-8f) ? 0.0f : pSurf;
-                        float norm = (pSurf > 0.0f) ? 1.0f / pSurf : 1.0f;
-                        float pdfSss = NoL * kInvPi * lp.subsurface * norm;
-                        float pdfSpec = specularPdfSpectral(NoH, VoH, roughness) * lp.specular * norm;
-                        float pdfDiff = (NoL * kInvPi) * lp.diffuse * norm;
-                        float pdfUsed = pdfSss * sss + pdfSpec * spec + pdfDiff * diff;
-                        prevBrdfPdf = pdfUsed;
-                        float brdfTotal = (brdfSpec * spec + brdfDiff * diff + brdfSss * sss);
-                        float contribution = (brdfTotal * NoL) / fmax_(pdfUsed, kMinDenominator);
-                        throughput *= contribution;
-                        float rr = fmin_(throughput, 0.95f);
-                        if (rand_float(seed) > rr) alive = false;
-                        else throughput /= rr;
-                    }
-
-                    if (alive && !lastBounce) {
-                        RayRec nr;
-                        nr.ox = no.x; nr.oy = no.y; nr.oz = no.z; nr.pad0 = 0.0f;
-                        nr.dx = L.x; nr.dy = L.y; nr.dz = L.z; nr.pad1 = kNeverStop;
-                        pb.rays[path] = nr;
-                        pb.stA[path] = make_float4(throughput, prevBrdfPdf, lambda, 0.0f);
-                        sB.x = radiance;
-                        sB.w = __uint_as_float(seed);
-                        pb.stB[path] = sB;
-                        wantExt = true;
-                    }
-                }
-            }
-        }
-        wavePush(wantShadow, qShadowOut, &next->shadow[sub].count, bt.P + path);
-        wavePush(wantExt, qOut, &next->ext[sub].count, path);
-    }
-    if (countOn) addShadedHits(pb, shaded);
-}
-
-// ---- k_resolve ---------------------------------------------------------------------------
-// Adds the batch's samples into the frame sum in sample order and, when a frame
-// completes, scales by 1/ssq^2 (Spectral: XYZ -> linear sRGB) and adds it to the
-// image sum (src/RayTracer.cpp:579-583, 1368-1378).  `partial` carries an
-// unfinished frame's sample sum across batches.
-template <bool SPECTRAL>
-__global__ __launch_bounds__(kBlock) void k_resolve(FrameParams fp, Batch bt, PathBuffers pb, float4 *accum, float4 *partial) {
-    const uint32_t stride = gridDim.x * kBlock;
-    for (uint32_t q = blockIdx.x * kBlock + threadIdx.x; q < fp.npt; q += stride) {
-        int x, y;
-        if (!pathPixel(fp, q, x, y)) continue;
-        const size_t px = (size_t)y * (size_t)fp.W + (size_t)x;
-        V3 c = v3s(0.0f);
-        float4 acc = accum[px];
-        bool accDirty = false;
-        for (uint32_t k = 0; k < bt.K; ++k) {
-            const uint32_t s = (bt.g0 + k) % fp.S;
-            if (s == 0u) {
-                c = v3s(0.0f);
-            } else if (k == 0u) {
-                float4 pc = partial[px];
-                c = v3(pc.x, pc.y, pc.z);
-            }
-            const uint32_t path = pathIndex(fp, bt, k, q);
-            const float4 sB = pb.stB[path];
-            if (SPECTRAL) {
-                const float lambda = pb.stA[path].z;
-                if (fp.hero) {   // hero_wavelengths_to_rgb, src/RayTracer.cpp:1274-1280: the fourth term and the mean
-                    const float4 sum = pb.neeC[path];
-                    c = c + (v3(sum.x, sum.y, sum.z) + cieXYZ(lambda) * (sB.x / fp.wlPdf)) / 4.0f;
-                } else {
-                    c = c + cieXYZ(lambda) * (sB.x / fp.wlPdf);
-                }
-            } else {
-                c = c + v3(sB.x, sB.y, sB.z);
-            }
-            if (s == fp.S - 1u) {
-                V3 col = (!SPECTRAL && !fp.stratified) ? c / (float)fp.rayPerPixel : c * (fp.rssq * fp.rssq);   // :592 / :582
-                if (SPECTRAL) {
-                    col = col / kCieYIntegral;
-                    col = xyzEToLinearSRGB(col);
-                }
-                acc.x += col.x;
-                acc.y += col.y;
-                acc.z += col.z;
-                acc.w += 1.0f;
-                accDirty = true;
-            } else if (k == bt.K - 1u) {
-                partial[px] = make_float4(c.x, c.y, c.z, 0.0f);
-            }
-        }
-        if (accDirty) accum[px] = acc;
-    }
-}
-
-// ---- k_display ---------------------------------------------------------------------------
-// The reference's screen pass (src/main.cpp:36-69) on the progressive mean:
-// clamp below at 0, ACES filmic curve, NaN / negative / infinite debug colours,
-// gamma 1/2.2; written as 8-bit RGBA (round to nearest).
-__global__ __launch_bounds__(kBlock) void k_display(const float4 *accum, uchar4 *out, uint32_t pixels) {
-    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < pixels; i += gridDim.x * kBlock) {
-        const float4 a = accum[i];
-        const float n = a.w > 0.0f ? a.w : 1.0f;
-        V3 c = vmax(v3(a.x / n, a.y / n, a.z / n), v3s(0.0f));
-        c = (c * (2.51f * c + v3s(0.03f))) / (c * (2.43f * c + v3s(0.59f)) + v3s(0.14f));
-        c = vclamp(c, 0.0f, 1.0f);
-        V3 o;
-        if (c.x != c.x || c.y != c.y || c.z != c.z) o = v3(1.0f, 0.0f, 0.0f);
-        else if (c.x < 0.0f || c.y < 0.0f || c.z < 0.0f) o = v3(0.0f, 1.0f, 0.0f);
-        else if (abs_(c.x) == inf() || abs_(c.y) == inf() || abs_(c.z) == inf()) o = v3(0.0f, 0.0f, 1.0f);
-        else o = v3(pow_(c.x, 1.0f / 2.2f), pow_(c.y, 1.0f / 2.2f), pow_(c.z, 1.0f / 2.2f));
-        out[i] = make_uchar4((unsigned char)(o.x * 255.0f + 0.5f), (unsigned char)(o.y * 255.0f + 0.5f),
-                             (unsigned char)(o.z * 255.0f + 0.5f), 255);
-    }
-}
-
-}  // namespace
+#include "rt_wavefront.h"
+#include "rt_kernels_frame.h"
+#include "rt_kernels_trace.h"
+#include "rt_kernels_shade.h"
 
 // ============================================================================================
 // Host side

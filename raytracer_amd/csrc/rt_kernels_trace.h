@@ -1,0 +1,566 @@
+// rt_kernels_trace.h — the persistent traversal kernel k_trace and its variants: binary trees in
+// the reference's visiting order, and the opt-in four-wide trees.
+#pragma once
+
+#include "rt_wavefront.h"
+
+using namespace rtd;
+
+namespace {
+
+// ---- k_trace ----------------------------------------------------------------------------
+// RayBoundingBoxDst, src/RayScene.cpp:417-431, with 1/direction hoisted per ray.
+__device__ __forceinline__ float slabDistance(V3 bmin, V3 bmax, V3 ro, V3 inv, float t) {
+    V3 tMin = (bmin - ro) * inv;
+    V3 tMax = (bmax - ro) * inv;
+    V3 t1 = v3(fminI_(tMin.x, tMax.x), fminI_(tMin.y, tMax.y), fminI_(tMin.z, tMax.z));
+    V3 t2 = v3(fmaxI_(tMin.x, tMax.x), fmaxI_(tMin.y, tMax.y), fmaxI_(tMin.z, tMax.z));
+    float nearD = fmax3_(t1.x, t1.y, t1.z);
+    float farD = fmin3_(t2.x, t2.y, t2.z);
+    // The reference returns early when nearD > t; as a select it is the same value without a branch.
+    return (!(nearD > t) && farD >= nearD && farD > 0.0f) ? nearD : 1e20f;
+}
+
+// Byte k of a word as float (v_cvt_f32_ubyteK).
+template <int K> __device__ __forceinline__ float byteAsFloat(uint32_t w) { return (float)((w >> (8 * K)) & 0xffu); }
+
+// Entry distance of child K of a four-wide node, 1e20 when the ray misses it or enters it
+// beyond `t`.  nx..fz are the words holding the planes the ray meets first / last on each axis,
+// (sx, bx) map a plane number q to the ray parameter q*sx + bx.
+typedef float float2v __attribute__((ext_vector_type(2)));
+template <int K>
+__device__ __forceinline__ float wideChildDistance(uint32_t nx, uint32_t ny, uint32_t nz, uint32_t fx, uint32_t fy, uint32_t fz,
+                                                   float2v sx, float2v sy, float2v sz, float2v bx, float2v by, float2v bz, float t) {
+    // (near, far) of one axis as one packed multiply-add
+    const float2v tx = __builtin_elementwise_fma((float2v){byteAsFloat<K>(nx), byteAsFloat<K>(fx)}, sx, bx);
+    const float2v ty = __builtin_elementwise_fma((float2v){byteAsFloat<K>(ny), byteAsFloat<K>(fy)}, sy, by);
+    const float2v tz = __builtin_elementwise_fma((float2v){byteAsFloat<K>(nz), byteAsFloat<K>(fz)}, sz, bz);
+    const float nearD = fmax3_(tx.x, ty.x, tz.x);
+    const float farD = fmin3_(tx.y, ty.y, tz.y);
+    return (nearD <= t && farD >= nearD && farD > 0.0f) ? nearD : 1e20f;
+}
+
+// Orders two (distance, reference) pairs by distance.
+__device__ __forceinline__ void orderPair(float &da, int32_t &ca, float &db, int32_t &cb) {
+    const bool swap = db < da;
+    const float dLo = swap ? db : da, dHi = swap ? da : db;
+    const int32_t cLo = swap ? cb : ca, cHi = swap ? ca : cb;
+    da = dLo; db = dHi; ca = cLo; cb = cHi;
+}
+
+// Alpha-cut rejection inside hitTriangle (src/RayScene.cpp:547-577).  Only
+// triangles flagged kTriAlphaTest at commit time come here.  The traversal kernel
+// runs it in a phase of its own, where no node or triangle temporaries are live.
+__device__ __forceinline__ bool alphaCutRejects(const SceneView &sc, const PackedTri &pt, V3 ro, V3 rd, float t) {
+    const ModelDesc &md = sc.modelDesc[pt.model & kTriModelMask];
+    const float *idw = sc.models + md.identBase + pt.ident * kIdentWords;
+    int32_t idx[3] = {f2i(idw[0]), f2i(idw[1]), f2i(idw[2])};
+    TriVerts tv;
+    loadTriVerts(sc, md.vertBase, idx, tv);
+    const float *m = sc.materials + pt.material * kMaterialWords;
+    int baseColor = f2i(m[1]);
+    float alphaCut = m[20];
+    V2 uv = cramerUV(tv.p[0], tv.p[1], tv.p[2], tv.uv[0], tv.uv[1], tv.uv[2], ro + t * rd);
+    int at = texelOffset(sc, baseColor, uv);
+    return sc.textures[at + 3] < alphaCut;
+}
+
+// Pins loaded values at this point of the program, so that the compiler cannot sink one of the
+// loads below a later branch (which turns one round trip to memory into two dependent ones).
+__device__ __forceinline__ void pinLoaded(const float4 &a, const float4 &b, const float4 &c) {
+    asm volatile("" : : "v"(a.x), "v"(a.w), "v"(b.x), "v"(b.w), "v"(c.x), "v"(c.w));
+}
+
+// The same for whole 16-byte values: each must sit in four consecutive registers here, which keeps
+// the compiler from re-cutting the record into loads that straddle the 16-byte pieces.
+typedef float float4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void pinLoaded(float4v &a, float4v &b, float4v &c) { asm volatile("" : "+v"(a), "+v"(b), "+v"(c)); }
+__device__ __forceinline__ float4 asFloat4(const float4v &v) { return make_float4(v.x, v.y, v.z, v.w); }
+
+// Per-lane traversal state of the refilling variant.
+struct LaneRay {
+    V3 ro, rd, inv;
+    float closest, afterPrimitives, tModel, maxT;
+    float tStop;   // any accepted hit closer than this ends the ray at once (occluded shadow ray)
+    float bestU, bestV, mU, mV;
+    uint32_t bestId, mBest, slot;
+    int32_t ref, model, sp;
+    // Alpha-cut variant only: a candidate hit on an alpha-tested triangle waits here for the
+    // texture lookup (pendTri != kMiss), and `resume` is where the leaf loop continues afterwards.
+    // (Recomputing t,u,v in the lookup phase and folding `resume` into the leaf reference saves
+    // four registers here but makes the compiler spill inside the main loop: measured slower.)
+    float pendT, pendU, pendV;
+    uint32_t pendTri, resume;
+};
+
+// Root references of the first models, copied to LDS by the traversal kernel: entering a model
+// then costs an LDS read instead of a round trip to memory on every ray's critical path.
+constexpr int kRootCache = 64;
+constexpr int32_t kNoRoot = (int32_t)0x80000000;   // model without nodes; not a valid child reference
+
+__device__ __forceinline__ bool enterModel(const SceneView &sc, const int32_t *rootLds, LaneRay &r, int m) {
+    for (; m < sc.modelsCount; ++m) {
+        int32_t root;
+        if (rootLds != nullptr && m < kRootCache) {
+            root = rootLds[m];
+        } else {
+            const ModelDesc &md = sc.modelDesc[m];
+            root = md.nodesCount > 0 ? md.rootRef : kNoRoot;
+        }
+        if (root == kNoRoot) continue;
+        r.model = m;
+        r.ref = root;
+        r.sp = 0;
+        r.tModel = 1e20f;
+        r.maxT = r.closest;
+        r.mBest = kMiss;
+        r.mU = 0.0f;
+        r.mV = 0.0f;
+        r.pendTri = kMiss;
+        r.resume = 0u;
+        return true;
+    }
+    return false;
+}
+
+// Analytic primitives, linear scan (hit(), src/RayScene.cpp:855-891); leaves the
+// closest primitive hit in the lane state.
+template <bool COUNT>
+__device__ __forceinline__ void intersectPrimitives(const SceneView &sc, LaneRay &r, uint32_t &cntTris) {
+    const V3 ro = r.ro, rd = r.rd;
+    float closest = 1e20f;
+    uint32_t bestId = kMiss;
+    float bestU = 0.0f, bestV = 0.0f;
+    int at = 0;
+    for (int pi = 0; pi < sc.objectCount; ++pi) {
+        const int type = ldi(sc.objects, at);
+        at += 2;
+        if (type == 0) {            // hitSphere, src/RayScene.cpp:441-466
+            V3 center = ld3(sc.objects, at);
+            float radius = ldw(sc.objects, at + 3);
+            at += 4;
+            V3 dir = center - ro;
+            float a = dot(rd, rd);
+            float h = dot(rd, dir);
+            float c = dot(dir, dir) - radius * radius;
+            float disc = h * h - a * c;
+            if (!(disc < 0.0f)) {
+                float sq = sqrt_(disc);
+                float t = (h - sq) / a;
+                bool ok = true;
+                if (t <= 1e-8f || t >= closest) {
+                    t = (h + sq) / a;
+                    if (t <= 1e-8f || t >= closest) ok = false;
+                }
+                if (ok) { closest = t; bestId = kPrimBit | (uint32_t)pi; bestU = 0.0f; bestV = 0.0f; }
+            }
+        } else if (type == 1) {     // hitQuad, src/RayScene.cpp:478-508 (+ cull, :870)
+            V3 qq = ld3(sc.objects, at), qu = ld3(sc.objects, at + 3), qv = ld3(sc.objects, at + 6);
+            bool cull = ldw(sc.objects, at + 9) != 0.0f;
+            at += 10;
+            V3 normal = cross(qu, qv);
+            if (!(cull && dot(rd, normal) > 0.0f)) {
+                float denom = dot(normal, rd);
+                float nn = dot(normal, normal);
+                if (!(abs_(denom) < kMinDenominator)) {
+                    float t = dot(normal, qq - ro) / denom;
+                    if (!(t < 1e-8f || t > closest || t >= closest)) {
+                        V3 rel = (ro + t * rd) - qq;
+                        float alpha = dot(normal, cross(rel, qv)) / nn;
+                        float beta = dot(normal, cross(qu, rel)) / nn;
+                        if (!(alpha < 0.0f || alpha > 1.0f || beta < 0.0f || beta > 1.0f)) {
+                            closest = t; bestId = kPrimBit | (uint32_t)pi; bestU = 0.0f; bestV = 0.0f;
+                        }
+                    }
+                }
+            }
+        } else if (type == 2) {     // top-level Triangle through hitTriangle
+            V3 A = ld3(sc.objects, at), B = ld3(sc.objects, at + 3), C = ld3(sc.objects, at + 6);
+            at += 18;
+            if (COUNT) cntTris++;
+            V3 ab = B - A, ac = C - A;
+            V3 nrm = cross(ab, ac);
+            float det = -dot(rd, nrm);
+            if (!(abs_(det) < 1e-8f)) {
+                V3 ao = ro - A;
+                V3 dao = cross(ao, rd);
+                float invDet = 1.0f / det;
+                float t = dot(ao, nrm) * invDet;
+                if (!(t < 0.0f || t > closest || t >= closest)) {
+                    float u = dot(ac, dao) * invDet;
+                    float v = -dot(ab, dao) * invDet;
+                    if (!(u < 0.0f || v < 0.0f || u + v > 1.0f)) {
+                        closest = t; bestId = kPrimBit | (uint32_t)pi; bestU = u; bestV = v;
+                    }
+                }
+            }
+        }
+    }
+    r.closest = closest;
+    r.afterPrimitives = closest;
+    r.bestId = bestId;
+    r.bestU = bestU;
+    r.bestV = bestV;
+}
+
+// Persistent traversal kernel: a wave keeps up to 64 rays in flight
+// and, whenever `refillLanes` or more lanes are idle, reserves that many queue
+// entries with one atomic and hands them to the idle lanes (refillLanes = 64
+// keeps whole 64-ray packets together, which is what coherent camera rays want;
+// incoherent rays run best around 32).  The traversal stack of each lane lives
+// in LDS ([entry][lane], conflict free).
+//
+// WIDE variants walk the models' four-wide trees instead: half as many dependent node loads per
+// ray.  They find the same closest hit (the later model winning a tie between models, as in the
+// reference), but not by the reference's visiting order, so between two triangles of one model at
+// the same distance the other one may win.  (One tree over all models was tried: fewer nodes per
+// ray but slower, because lanes then mix the small models' leaves with the large model's inner
+// nodes and the two phases of the loop run emptier.)
+template <bool COUNT, int STACK, bool ALPHA, bool PRIMS, bool ROOTS, bool WIDE>
+__global__ __launch_bounds__(kBlock, WIDE ? (ALPHA ? RT_WWIDE_ALPHA : RT_WWIDE)
+                                          : (STACK <= 20 ? (ALPHA ? RT_WALPHA : PRIMS ? 7 : RT_W20) : STACK <= 24 ? (ALPHA ? (RT_WALPHA < 6 ? RT_WALPHA : 6) : 6) : 5)) void k_trace(SceneView sc, PathBuffers pb, int extParity, int stage, int refillLanes, int innerShare) {
+    __shared__ int32_t stackLds[kBlock / 64][STACK][64];
+    // ROOTS variants (scenes with more than two models): the models' root references sit in LDS.
+    // With one or two models the descriptor loads hit the L1 and the plain variant is faster
+    // (the table costs registers: -3 %); with six models the table gives +10 %.
+    __shared__ int32_t rootTable[ROOTS ? kRootCache : 1];
+    const uint32_t lane = laneId();
+    int32_t(*stack)[64] = stackLds[threadIdx.x >> 6];
+    const int32_t *rootLds = ROOTS ? rootTable : nullptr;
+    if (ROOTS && (int)threadIdx.x < kRootCache) {
+        int32_t root = kNoRoot;
+        if ((int)threadIdx.x < sc.modelsCount) {
+            const ModelDesc &md = sc.modelDesc[threadIdx.x];
+            if (md.nodesCount > 0) root = md.rootRef;
+        }
+        rootTable[threadIdx.x] = root;
+    }
+    if (ROOTS) __syncthreads();
+
+    Stage *st = &pb.stages[stage];
+    const uint32_t *qExt = extParity >= 0 ? pb.qExt[extParity] : nullptr;
+    const int firstSource = qExt ? 0 : kSubQueues;
+    const int numSources = 2 * kSubQueues - firstSource;
+    const uint32_t waveId = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    int source = firstSource + (int)(waveId % (uint32_t)numSources);
+    bool drained = false;    // every source has been seen empty
+
+    uint32_t cntNodes = 0, cntTris = 0, maxSp = 0;
+    bool active = false;
+    LaneRay r;
+    r.slot = 0;
+    // Four-wide variants: this lane's column of the stack part that does not fit in LDS.
+    int32_t *overflow = WIDE ? pb.overflow + (size_t)waveId * pb.overflowDepth * 64 + lane : nullptr;
+    // The four-wide variants run at the edge of their register budget: the lane's column of the LDS
+    // stack is addressed from the lane number re-read on the spot (two instructions) rather than from
+    // a value kept for the whole kernel, which the compiler would keep in scratch memory and reload
+    // at every push.
+    int32_t *const waveStack = &stackLds[0][0][0] + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * (STACK * 64);
+    auto stackSlot = [&](int32_t sp) -> int32_t * { return WIDE ? waveStack + sp * 64 + laneIdNow() : &stack[sp][lane]; };
+    auto pushWide = [&](int32_t ref) {
+        if (r.sp < STACK) *stackSlot(r.sp) = ref;
+        else overflow[(size_t)(r.sp - STACK) * 64] = ref;
+        r.sp++;
+    };
+    // Opens a four-wide node: the nearest child the ray enters becomes the lane's next reference,
+    // the others go on the stack with the farthest at the bottom.  True when no child is entered.
+    // Children are culled with maxT, the closest hit of this AND the earlier models (a triangle at
+    // exactly that distance still replaces it, so boxes entered at maxT stay in); the reference
+    // culls with the current model's hit only and walks every model's tree from the top.
+    auto openWideNode = [&](const float4 &n0, const float4 &n1, const float4 &n2, const float4 &n3) -> bool {
+        if (COUNT) cntNodes++;
+        const float sx1 = n1.x * r.inv.x, sy1 = n1.y * r.inv.y, sz1 = n1.z * r.inv.z;
+        const float bx1 = (n0.x - r.ro.x) * r.inv.x, by1 = (n0.y - r.ro.y) * r.inv.y, bz1 = (n0.z - r.ro.z) * r.inv.z;
+        const float2v sx = {sx1, sx1}, sy = {sy1, sy1}, sz = {sz1, sz1}, bx = {bx1, bx1}, by = {by1, by1}, bz = {bz1, bz1};
+        const uint32_t lox = __float_as_uint(n2.x), loy = __float_as_uint(n2.y), loz = __float_as_uint(n2.z);
+        const uint32_t hix = __float_as_uint(n3.x), hiy = __float_as_uint(n3.y), hiz = __float_as_uint(n3.z);
+        const bool ngx = r.inv.x < 0.0f, ngy = r.inv.y < 0.0f, ngz = r.inv.z < 0.0f;
+        const uint32_t nx = ngx ? hix : lox, fx = ngx ? lox : hix;
+        const uint32_t ny = ngy ? hiy : loy, fy = ngy ? loy : hiy;
+        const uint32_t nz = ngz ? hiz : loz, fz = ngz ? loz : hiz;
+        float d0 = wideChildDistance<0>(nx, ny, nz, fx, fy, fz, sx, sy, sz, bx, by, bz, r.maxT);
+        float d1 = wideChildDistance<1>(nx, ny, nz, fx, fy, fz, sx, sy, sz, bx, by, bz, r.maxT);
+        float d2 = wideChildDistance<2>(nx, ny, nz, fx, fy, fz, sx, sy, sz, bx, by, bz, r.maxT);
+        float d3 = wideChildDistance<3>(nx, ny, nz, fx, fy, fz, sx, sy, sz, bx, by, bz, r.maxT);
+        int32_t c0 = __float_as_int(n0.w), c1 = __float_as_int(n1.w), c2 = __float_as_int(n2.w), c3 = __float_as_int(n3.w);
+        orderPair(d0, c0, d1, c1);
+        orderPair(d2, c2, d3, c3);
+        orderPair(d0, c0, d2, c2);
+        orderPair(d1, c1, d3, c3);
+        orderPair(d1, c1, d2, c2);
+        if (!(d0 < 1e20f)) return true;
+        if (d3 < 1e20f) { pushWide(c3); }
+        if (d2 < 1e20f) { pushWide(c2); }
+        if (d1 < 1e20f) { pushWide(c1); }
+        r.ref = c0;
+        return false;
+    };
+    // Möller–Trumbore as hitTriangle writes it (src/RayScene.cpp:510-545); returns true when the
+    // hit waits for its alpha-cut lookup.
+    auto testTriangle = [&](uint32_t ti, const float4 &q0, const float4 &q1, const float4 &q2) -> bool {
+        if (COUNT) cntTris++;
+        const V3 A = v3(q0.x, q0.y, q0.z), ab = v3(q1.x, q1.y, q1.z), ac = v3(q2.x, q2.y, q2.z);
+        const V3 nrm = cross(ab, ac);
+        const float det = -dot(r.rd, nrm);
+        if (abs_(det) < 1e-8f) return false;
+        const V3 ao = r.ro - A;
+        const V3 dao = cross(ao, r.rd);
+        const float invDet = 1.0f / det;
+        const float t = dot(ao, nrm) * invDet;
+        if (t < 0.0f || t > r.maxT) return false;
+        // A later model's triangle at exactly the closest distance so far replaces the hit, a
+        // triangle of the same model does not (src/RayScene.cpp:535, :405-406).  The four-wide walk
+        // keeps one distance for both tests: maxT is this model's hit once mBest is set.
+        if (WIDE ? (r.mBest != kMiss && t == r.maxT) : (t >= r.tModel)) return false;
+        const float u = dot(ac, dao) * invDet;
+        const float v = -dot(ab, dao) * invDet;
+        if (u < 0.0f || v < 0.0f || u + v > 1.0f) return false;
+        if (ALPHA && (__float_as_int(q1.w) & kTriAlphaTest)) {
+            r.pendT = t;
+            r.pendU = u;
+            r.pendV = v;
+            r.pendTri = ti;
+            return true;
+        }
+        if (!WIDE) r.tModel = t;   // the four-wide walk keeps its closest hit in maxT alone
+        r.maxT = t;
+        r.mBest = ti;
+        r.mU = u;
+        r.mV = v;
+        return false;
+    };
+
+    for (;;) {
+        if (COUNT && active) maxSp = max(maxSp, (uint32_t)r.sp);
+        const unsigned long long idleMask = __ballot(!active);
+        const int nIdle = __popcll(idleMask);
+        if (!drained && nIdle >= refillLanes) {
+            // `source` is the same in every lane; saying so keeps the queue header in scalar registers
+            // and turns the load of its length into a scalar load.
+            const int src = __builtin_amdgcn_readfirstlane(source);
+            SubQueue *sq = (src < kSubQueues) ? &st->ext[src] : &st->shadow[src - kSubQueues];
+            const uint32_t n = sq->count;
+            const int leader = __ffsll((long long)idleMask) - 1;
+            uint32_t base = n;
+            if (n != 0u) {
+                if ((int)lane == leader) base = atomicAdd(&sq->cursor, (uint32_t)nIdle);
+                base = __shfl(base, leader);
+            }
+            if (base >= n) {
+                bool has = false;
+                if ((int)lane >= firstSource && (int)lane < 2 * kSubQueues) {
+                    SubQueue *o = ((int)lane < kSubQueues) ? &st->ext[lane] : &st->shadow[lane - kSubQueues];
+                    has = __hip_atomic_load(&o->cursor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < o->count;
+                }
+                const unsigned long long live = __ballot(has);
+                if (live == 0ull) {
+                    drained = true;
+                } else {
+                    int pick = (int)(waveId % (uint32_t)__popcll(live));
+                    unsigned long long m = live;
+                    while (pick-- > 0) m &= m - 1ull;
+                    source = __ffsll((long long)m) - 1;
+                }
+                if (nIdle == 64) {
+                    if (drained) break;
+                    continue;
+                }
+            } else {
+                const uint32_t mine = base + (uint32_t)__popcll(idleMask & ((1ull << lane) - 1ull));
+                if (!active && mine < n) {
+                    const uint32_t *q = (src < kSubQueues) ? qExt + (size_t)src * pb.subCap
+                                                             : pb.qShadow + (size_t)(src - kSubQueues) * pb.subCap;
+                    r.slot = q[mine];
+                    const float4 *rp = reinterpret_cast<const float4 *>(&pb.rays[r.slot]);
+                    const float4 r0 = rp[0], r1 = rp[1];
+                    r.ro = v3(r0.x, r0.y, r0.z);
+                    r.rd = v3(r1.x, r1.y, r1.z);
+                    if (WIDE) {
+                        // Only box tests use inv here, and the boxes carry a margin: the one-instruction
+                        // reciprocal will do.  Plane numbers are scaled by inv, so keep it finite (a
+                        // direction component of zero then behaves like a very small one of the same sign).
+                        r.inv = v3(__builtin_amdgcn_rcpf(r.rd.x), __builtin_amdgcn_rcpf(r.rd.y), __builtin_amdgcn_rcpf(r.rd.z));
+                        r.inv = v3(fminI_(fmaxI_(r.inv.x, -1e18f), 1e18f), fminI_(fmaxI_(r.inv.y, -1e18f), 1e18f), fminI_(fmaxI_(r.inv.z, -1e18f), 1e18f));
+                    } else {
+                        r.inv = v3(1.0f / r.rd.x, 1.0f / r.rd.y, 1.0f / r.rd.z);
+                    }
+                    r.tStop = r1.w;
+                    if (PRIMS) {
+                        intersectPrimitives<COUNT>(sc, r, cntTris);
+                        active = !(r.closest < r.tStop) && enterModel(sc, rootLds, r, 0);
+                        if (!active) {   // no models (or already occluded): the primitive result is final
+                            HitRec rec;
+                            rec.t = r.closest; rec.u = r.bestU; rec.v = r.bestV; rec.id = r.bestId;
+                            *reinterpret_cast<float4 *>(&pb.hits[r.slot]) = *reinterpret_cast<const float4 *>(&rec);
+                        }
+                    } else {
+                        // Without analytic primitives the record starts as a miss and is
+                        // overwritten whenever a model ends with a closer hit, so the best
+                        // hit need not be carried in registers.
+                        r.closest = 1e20f;
+                        HitRec rec;
+                        rec.t = 1e20f; rec.u = 0.0f; rec.v = 0.0f; rec.id = kMiss;
+                        *reinterpret_cast<float4 *>(&pb.hits[r.slot]) = *reinterpret_cast<const float4 *>(&rec);
+                        active = enterModel(sc, rootLds, r, 0);
+                    }
+                }
+            }
+        } else if (nIdle == 64) {
+            break;
+        }
+
+        // One phase per iteration, chosen for the whole wave: open inner nodes while
+        // at least `innerShare`/64 of the active lanes sit on one, otherwise test the
+        // leaves the other lanes are parked on.  Lanes of the other kind wait, so each
+        // phase runs with most lanes enabled instead of both code paths every iteration.
+        const bool onInner = active && r.ref >= 0;
+        int nActive = 64 - __popcll(__ballot(!active));
+        const int nInner = __popcll(__ballot(onInner));
+        if (ALPHA) {
+            // Third phase: candidate hits on alpha-tested triangles wait until eight lanes have one
+            // (or nothing else is left to do) and are then resolved together; the texture lookup
+            // needs many registers, and here none of the node/triangle temporaries are live.
+            const bool pending = active && r.pendTri != kMiss;
+            const int nPending = __popcll(__ballot(pending));
+            if (nPending > 0 && (nPending >= 8 || nPending == nActive)) {
+                if (pending) {
+                    if (!alphaCutRejects(sc, sc.tris[r.pendTri], r.ro, r.rd, r.pendT)) {
+                        if (!WIDE) r.tModel = r.pendT;
+                        r.maxT = r.pendT;
+                        r.mBest = r.pendTri;
+                        r.mU = r.pendU;
+                        r.mV = r.pendV;
+                    }
+                    r.resume = r.pendTri - ((~(uint32_t)r.ref) >> 2) + 1u;
+                    r.pendTri = kMiss;
+                }
+                continue;
+            }
+            nActive -= nPending;
+        }
+        const bool innerPhase = nInner * 64 >= nActive * innerShare;
+        bool pop = false, occluded = false;
+        if (innerPhase) {
+            if (WIDE) {
+                if (onInner) {
+                    const float4 *np = reinterpret_cast<const float4 *>(&sc.wnodes[r.ref]);
+                    const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+                    pop = openWideNode(n0, n1, n2, n3);
+                }
+            } else if (onInner) {
+                if (COUNT) cntNodes++;
+                const float4 *np = reinterpret_cast<const float4 *>(&sc.nodes[r.ref]);
+                const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+                const int32_t left = __float_as_int(n0.w), right = __float_as_int(n1.w);
+                const float dL = slabDistance(v3(n0.x, n0.y, n0.z), v3(n1.x, n1.y, n1.z), r.ro, r.inv, r.tModel);
+                const float dR = slabDistance(v3(n2.x, n2.y, n2.z), v3(n3.x, n3.y, n3.z), r.ro, r.inv, r.tModel);
+                const bool pushL = dL < r.tModel, pushR = dR < r.tModel;
+                const bool leftFirst = dL < dR;
+                const bool takeNear = leftFirst ? pushL : pushR;
+                const bool takeFar = leftFirst ? pushR : pushL;
+                const int32_t nearRef = leftFirst ? left : right;
+                const int32_t farRef = leftFirst ? right : left;
+                pop = true;
+                if (takeNear) {
+                    if (takeFar && r.sp < STACK) stack[r.sp++][lane] = farRef;
+                    r.ref = nearRef;
+                    pop = false;
+                } else if (takeFar) {
+                    r.ref = farRef;
+                    pop = false;
+                }
+            }
+        } else if (active && r.ref < 0 && !(ALPHA && r.pendTri != kMiss)) {
+            const uint32_t code = ~(uint32_t)r.ref;
+            const uint32_t first = code >> 2, ntri = code & 3u;
+            bool parked = false;
+            if (WIDE && !ALPHA) {
+                // The usual leaf holds one or two triangles: fetch both in one round trip (the binary
+                // variants have no registers to spare for this: -10 % there, +2 % here).
+                const float4v *tp = reinterpret_cast<const float4v *>(&sc.tris[first]);
+                if (ntri > 0u) {
+                    const bool two = ntri > 1u;
+                    float4v a0 = tp[0], a1 = tp[1], a2 = tp[2];
+                    float4v b0 = a0, b1 = a1, b2 = a2;
+                    if (two) { b0 = tp[3]; b1 = tp[4]; b2 = tp[5]; }
+                    pinLoaded(a0, a1, a2);
+                    pinLoaded(b0, b1, b2);
+                    testTriangle(first, asFloat4(a0), asFloat4(a1), asFloat4(a2));
+                    if (two) testTriangle(first + 1u, asFloat4(b0), asFloat4(b1), asFloat4(b2));
+                    for (uint32_t k = 2u; k < ntri; ++k) {
+                        float4v q0 = tp[3 * k], q1 = tp[3 * k + 1], q2 = tp[3 * k + 2];
+                        pinLoaded(q0, q1, q2);
+                        testTriangle(first + k, asFloat4(q0), asFloat4(q1), asFloat4(q2));
+                    }
+                }
+            } else {
+                for (uint32_t k = ALPHA ? r.resume : 0u; k < ntri; ++k) {
+                    const uint32_t ti = first + k;
+                    const float4 *tp = reinterpret_cast<const float4 *>(&sc.tris[ti]);
+                    const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
+                    pinLoaded(q0, q1, q2);   // all three in one round trip, before the determinant test
+                    if (testTriangle(ti, q0, q1, q2)) {
+                        parked = true;
+                        break;
+                    }
+                }
+            }
+            if (!parked) {
+                if (ALPHA) r.resume = 0u;
+                pop = true;
+                occluded = WIDE ? (r.mBest != kMiss && r.maxT < r.tStop) : (r.tModel < r.tStop);
+            }
+        }
+        if (pop) {
+            if (r.sp > 0 && !occluded) {
+                --r.sp;
+                if (WIDE && r.sp >= STACK) r.ref = overflow[(size_t)(r.sp - STACK) * 64];
+                else r.ref = *stackSlot(r.sp);
+            } else {
+                if (r.mBest != kMiss) {
+                    const float tHit = WIDE ? r.maxT : r.tModel;
+                    r.closest = tHit;
+                    if (PRIMS) {
+                        r.bestId = r.mBest;
+                        r.bestU = r.mU;
+                        r.bestV = r.mV;
+                    } else {
+                        HitRec rec;
+                        rec.t = tHit; rec.u = r.mU; rec.v = r.mV; rec.id = r.mBest;
+                        *reinterpret_cast<float4 *>(&pb.hits[r.slot]) = *reinterpret_cast<const float4 *>(&rec);
+                    }
+                }
+                if (occluded || !enterModel(sc, rootLds, r, r.model + 1)) {
+                    if (PRIMS) {
+                        uint32_t id = r.bestId;
+                        if (id != kMiss && (id & kPrimBit) == 0u && !(r.afterPrimitives > r.closest)) id |= kNoTexBit;
+                        HitRec rec;
+                        rec.t = r.closest; rec.u = r.bestU; rec.v = r.bestV; rec.id = id;
+                        *reinterpret_cast<float4 *>(&pb.hits[r.slot]) = *reinterpret_cast<const float4 *>(&rec);
+                    }
+                    active = false;
+                }
+            }
+        }
+    }
+
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        unsigned long long total = 0;
+        for (int q = 0; q < kSubQueues; ++q) total += (qExt ? st->ext[q].count : 0u) + st->shadow[q].count;
+        atomicAdd(&pb.counters[0], total);
+    }
+    if (COUNT) {
+        for (int off = 32; off > 0; off >>= 1) {
+            cntNodes += __shfl_down(cntNodes, off);
+            cntTris += __shfl_down(cntTris, off);
+            maxSp = max(maxSp, (uint32_t)__shfl_down(maxSp, off));
+        }
+        if (lane == 0) {
+            atomicAdd(&pb.counters[1], (unsigned long long)cntNodes);
+            atomicAdd(&pb.counters[2], (unsigned long long)cntTris);
+            atomicMax(&pb.counters[4], (unsigned long long)maxSp);
+        }
+    }
+}
+
+}  // namespace

@@ -1,0 +1,148 @@
+// rt_wavefront.h — state shared by the kernels of the wavefront pipeline: per-frame parameters,
+// the batch descriptor, the sub-queues of every bounce, the per-path buffers, and the wave-level
+// queue append.  Included by rt_hip.hip only (one translation unit; hence the unnamed namespace).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "rt_bsdf.h"
+
+using namespace rtd;
+
+namespace {
+
+#ifndef RT_W20
+#define RT_W20 7
+#endif
+#ifndef RT_WALPHA
+#define RT_WALPHA 6   // alpha-cut variants: 80 VGPRs; at 7 waves/SIMD (72) they spill inside the main loop
+#endif
+#ifndef RT_WWIDE
+#define RT_WWIDE 7     // waves/SIMD of the four-wide variants (72 VGPRs with 40 B of spills: +4 % over 6 waves without)
+#endif
+#ifndef RT_WWIDE_ALPHA
+#define RT_WWIDE_ALPHA 5
+#endif
+constexpr int kStackDepth = 32;      // int stack[32], src/RayScene.cpp:682
+#ifndef RT_WSTACK
+#define RT_WSTACK 16
+#endif
+constexpr int kWideStack = RT_WSTACK;   // LDS stack entries of the four-wide variants; deeper entries go to memory
+constexpr int kBlock = 256;
+constexpr int kMaxBounces = 62;      // stages kept on the device
+// Default ceiling of paths in flight per batch (~190 B of device memory each).  Every kernel of
+// a batch ends with a drain tail in which most of the chip idles, so few large batches beat many
+// small ones: the default bench step (1920x1080 x 64 sample planes) fits in one batch.
+constexpr uint32_t kDefaultMaxPaths = 128u << 20;
+constexpr float kNeverStop = -1e30f;  // RayRec::pad1 of rays that must find their closest hit
+
+// Per-frame uniforms plus values derived from them once on the host.
+struct FrameParams {
+    float fov, resX, resY;
+    V3 position, forward, right, up;
+    int32_t bounces, rayPerPixel;
+    V3 sky;
+    // fragment main(), src/RayTracer.cpp:545-563
+    float rImgX, rImgY, focalLength, halfWidth, halfHeight;
+    int32_t ssq;
+    float rssq, wlDt, wlPdf;
+    int32_t W, H, tilesX, tilesY;
+    uint32_t npt;       // padded pixels per sample plane: tilesX*tilesY*64
+    uint32_t S;         // samples per frame = ssq*ssq
+    int32_t shadowEarlyOut;   // RGB shadow rays stop at the first hit that already proves occlusion
+    int32_t spectralPdfAsWritten;   // Spectral: area pdf without the light-selection probability
+    int32_t hero;             // Spectral: four wavelengths per camera sample (HERO_WAVELENGTH_ENABLE, src/RayTracer.cpp:607)
+    int32_t nee;              // next-event estimation on (ENABLE_NEE, src/RayTracer.cpp:24, 606)
+    int32_t stratified;       // RGB: stratified samples (`#if 1`, src/RayTracer.cpp:569); 0 = its #else branch, S = rayPerPixel
+    // Tile-split sharding: this context renders only the 8x8 tiles whose row-major
+    // index i satisfies i % tileStride == tileOffset (all tiles when stride is 1).
+    uint32_t tileOffset, tileStride;
+};
+
+struct Batch {
+    uint32_t g0;         // first global sample index (frame-major, sample-minor)
+    uint32_t K;          // sample planes in this batch
+    uint32_t firstFrame, frameStride;
+    uint32_t P;          // capacity in paths; shadow-ray slots start at P
+    uint32_t planesInner;   // path order: 1 = tile-major (all K samples of a tile adjacent), 0 = plane-major
+};
+
+// Path index of sample plane k (0..K-1) of padded pixel q.  Tile-major order keeps the rays in
+// flight at any moment inside a small screen region, so they share the tree nodes they open.
+__device__ __forceinline__ uint32_t pathIndex(const FrameParams &fp, const Batch &bt, uint32_t k, uint32_t q);
+
+
+// Every ray queue is split into kSubQueues sub-queues, each with its length and
+// its consumer cursor on a 128-byte line of its own: a single queue word would
+// take one atomic per wave from every CU and saturates at ~90 atomics/us.
+// Block b of any producer/consumer kernel owns sub-queue b % kSubQueues; the
+// persistent traversal kernel drains all of them.
+#ifndef RT_SUBQ
+#define RT_SUBQ 32
+#endif
+constexpr int kSubQueues = RT_SUBQ;
+static_assert(2 * kSubQueues <= 64, "the traversal kernel scans all sources with one wave-wide load");
+struct __attribute__((aligned(128))) SubQueue {
+    uint32_t count;      // entries appended by the producer kernel
+    uint32_t cursor;     // next entry the traversal kernel hands out
+    uint32_t pad[30];
+};
+// Queues of one bounce, all device resident.
+struct Stage {
+    SubQueue ext[kSubQueues];      // extension rays entering this bounce
+    SubQueue shadow[kSubQueues];   // shadow rays produced by the previous bounce
+};
+
+struct PathBuffers {
+    RayRec *rays;        // [2P]  extension rays [0,P), shadow rays [P,2P)
+    HitRec *hits;        // [2P]
+    float4 *stA;         // [P]   RGB: throughput.rgb, prevBrdfPdf      Spectral: throughput, prevBrdfPdf, lambda, -
+    float4 *stB;         // [P]   RGB: radiance.rgb, seed bits          Spectral: radiance, -, -, seed bits
+    float4 *neeA, *neeB, *neeC;   // [P] pending NEE term of the current bounce
+    uint32_t *qExt[2];   // [kSubQueues * subCap] each, ping-pong by bounce parity
+    uint32_t *qShadow;   // [kSubQueues * subCap]
+    uint32_t subCap;     // capacity of one sub-queue
+    Stage *stages;       // [kMaxBounces + 2]
+    unsigned long long *counters;  // [8]: 0 rays, 1 nodeVisits, 2 triTests, 3 shadedHits, 4 deepest traversal stack
+    // Four-wide traversal only: stack entries beyond the LDS part, [wave][overflowDepth][64].
+    int32_t *overflow;
+    uint32_t overflowDepth;
+};
+
+__device__ __forceinline__ uint32_t laneId() { return threadIdx.x & 63u; }
+// The lane number from the execution-mask counters; volatile, so every use re-reads it.
+__device__ __forceinline__ uint32_t laneIdNow() {
+    uint32_t x;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(x));
+    return x;
+}
+
+// Appends `value` for every lane with `want`; one atomic per wave.  Must be
+// called by all lanes of the wave.
+__device__ __forceinline__ void wavePush(bool want, uint32_t *queue, uint32_t *count, uint32_t value) {
+    unsigned long long mask = __ballot(want);
+    if (mask == 0ull) return;
+    uint32_t lane = laneId();
+    int leader = __ffsll((long long)mask) - 1;
+    uint32_t base = 0;
+    if ((int)lane == leader) base = atomicAdd(count, (uint32_t)__popcll(mask));
+    base = __shfl(base, leader);
+    if (want) queue[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = value;
+}
+
+// Path index -> pixel.  64 consecutive paths form one 8x8 pixel tile so a wave
+// of primary rays is spatially compact.
+__device__ __forceinline__ bool pathPixel(const FrameParams &fp, uint32_t q, int &x, int &y) {
+    uint32_t tile = q >> 6, l = q & 63u;
+    x = (int)(tile % (uint32_t)fp.tilesX) * 8 + (int)(l & 7u);
+    y = (int)(tile / (uint32_t)fp.tilesX) * 8 + (int)(l >> 3);
+    return x < fp.W && y < fp.H && (tile % fp.tileStride) == fp.tileOffset;
+}
+
+__device__ __forceinline__ uint32_t pathIndex(const FrameParams &fp, const Batch &bt, uint32_t k, uint32_t q) {
+    return bt.planesInner ? ((((q >> 6) * bt.K + k) << 6) | (q & 63u)) : k * fp.npt + q;
+}
+
+}  // namespace
