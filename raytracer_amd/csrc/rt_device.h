@@ -4,7 +4,8 @@
 //   * the five raw word streams exactly as the host serialised them (used by the
 //     shading kernels, which touch each hit once), and
 //   * a traversal re-pack built at commit time: 64-byte inner nodes holding both
-//     child boxes, and 48-byte triangle records (A, B-A, C-A + ids).
+//     child boxes, 48-byte triangle records (A, B-A, C-A + ids), and 64-byte shading
+//     records (vertex normals and texture coordinates) under the same triangle index.
 // Every function cites the reference GLSL it reproduces (paths in the reference tree).
 #pragma once
 
@@ -43,6 +44,17 @@ struct __attribute__((aligned(16))) PackedTri {
     float ac[3]; int32_t ident;      // C - A,      identifier index inside the model (leaf order)
 };
 static_assert(sizeof(PackedTri) == 48, "triangle record must be 48 bytes");
+// What shading needs of a triangle besides PackedTri, under the same index: the vertex normals and
+// texture coordinates gathered from the vertex stream at commit time.  A hit then costs two
+// independent fetches (112 contiguous bytes) instead of the chain triangle -> identifier -> three
+// vertices.
+struct __attribute__((aligned(64))) PackedShade {
+    float n0[3], n1[3], n2[3];
+    float uv0[2], uv1[2], uv2[2];
+    int32_t hasTextures;         // the identifier's texture flag (src/RayScene.cpp:659)
+};
+static_assert(sizeof(PackedShade) == 64, "shading record must be one 64-byte line");
+
 constexpr int32_t kTriAlphaTest = 1 << 30;  // triangle needs the alpha-cut texture test
 constexpr int32_t kTriModelMask = (1 << 30) - 1;
 
@@ -62,6 +74,7 @@ struct SceneView {
     const PackedNode *nodes;
     const WideNode *wnodes;     // four-wide tree, null unless that mode is on
     const PackedTri *tris;
+    const PackedShade *shade;   // [triangle], same index as tris
     const ModelDesc *modelDesc;
     int32_t objectCount, modelsCount, lightSourcesCount;
 };
@@ -167,8 +180,9 @@ RT_FN int texelOffset(const SceneView &sc, int header, V2 uv) {
 }
 
 // Barycentric UV interpolation used for texturing (Cramer form, src/RayScene.cpp:764-780).
-RT_FN V2 cramerUV(V3 a, V3 b, V3 c, V2 ta, V2 tb, V2 tc, V3 p) {
-    V3 e0 = b - a, e1 = c - a, vp = p - a;
+// e0 = B - A and e1 = C - A are the differences the re-pack stored (the same fp32 subtractions).
+RT_FN V2 cramerUV(V3 a, V3 e0, V3 e1, V2 ta, V2 tb, V2 tc, V3 p) {
+    V3 vp = p - a;
     float d00 = dot(e0, e0), d01 = dot(e0, e1), d11 = dot(e1, e1), d20 = dot(vp, e0), d21 = dot(vp, e1);
     float denom = d00 * d11 - d01 * d01;
     float v = (d11 * d20 - d01 * d21) / denom;
@@ -249,24 +263,24 @@ RT_FN HitInfoD resolveHit(const SceneView &sc, V3 ro, V3 rd, const HitRec &h) {
     }
 
     const PackedTri &pt = sc.tris[h.id & kIndexMask];
+    const PackedShade &ps = sc.shade[h.id & kIndexMask];
     const ModelDesc &md = sc.modelDesc[pt.model & kTriModelMask];
-    const float *idw = sc.models + md.identBase + pt.ident * kIdentWords;
-    int32_t idx[3] = {f2i(idw[0]), f2i(idw[1]), f2i(idw[2])};
-    int materialIndex = f2i(idw[3]);
-    bool hasTextures = idw[4] != 0.0f;
-    TriVerts tv;
-    loadTriVerts(sc, md.vertBase, idx, tv);
+    const int materialIndex = pt.material;
+    const bool hasTextures = ps.hasTextures != 0;
+    const V3 vertexA = v3(pt.a[0], pt.a[1], pt.a[2]);
+    const V3 edgeAB = v3(pt.ab[0], pt.ab[1], pt.ab[2]), edgeAC = v3(pt.ac[0], pt.ac[1], pt.ac[2]);
+    const V3 n0 = v3(ps.n0[0], ps.n0[1], ps.n0[2]), n1 = v3(ps.n1[0], ps.n1[1], ps.n1[2]), n2 = v3(ps.n2[0], ps.n2[1], ps.n2[2]);
+    const V2 uv0 = v2(ps.uv0[0], ps.uv0[1]), uv1 = v2(ps.uv1[0], ps.uv1[1]), uv2 = v2(ps.uv2[0], ps.uv2[1]);
 
-    V3 edgeAB = tv.p[1] - tv.p[0], edgeAC = tv.p[2] - tv.p[0];
     V3 geometric = cross(edgeAB, edgeAC);
-    info.normal = triangleNormal(tv.n[0], tv.n[1], tv.n[2], geometric, h.u, h.v);
+    info.normal = triangleNormal(n0, n1, n2, geometric, h.u, h.v);
     info.front_face = dot(rd, info.normal) < 0.0f;
     info.area = 0.5f * length(geometric);                       // triArea, src/RayScene.cpp:677-679
     info.modelLightCounts = md.lightSourcesCount;
     info.mat = loadMaterial(sc, materialIndex);
 
     if (hasTextures && (h.id & kNoTexBit) == 0u) {                 // src/RayScene.cpp:763-844
-        V2 uv = cramerUV(tv.p[0], tv.p[1], tv.p[2], tv.uv[0], tv.uv[1], tv.uv[2], info.point);
+        V2 uv = cramerUV(vertexA, edgeAB, edgeAC, uv0, uv1, uv2, info.point);
         MaterialD &m = info.mat;
         if (m.baseColorTexture != -1) {
             int at = texelOffset(sc, m.baseColorTexture, uv);
@@ -281,7 +295,7 @@ RT_FN HitInfoD resolveHit(const SceneView &sc, V3 ro, V3 rd, const HitRec &h) {
         if (m.normalTexture != -1) {
             // Tangent frame from the triangle's UVs (src/RayScene.cpp:597-621); the
             // normal map is skipped when they do not define one.
-            V2 d1 = tv.uv[1] - tv.uv[0], d2 = tv.uv[2] - tv.uv[0];
+            V2 d1 = uv1 - uv0, d2 = uv2 - uv0;
             float uvDet = d1.x * d2.y - d2.x * d1.y;
             if (abs_(uvDet) > kMinDenominator) {
                 float f = 1.0f / uvDet;

@@ -70,6 +70,7 @@ struct rt_ctx {
     bool wideBvh = false;
     int wideStackNeed = 0;          // most stack entries a ray can hold in the four-wide tree
     PackedTri *dTris = nullptr;
+    PackedShade *dShade = nullptr;
     ModelDesc *dModelDesc = nullptr;
     std::vector<PackedTri> hTris;   // kept for id decoding in rt_trace_primary
     SceneView view{};
@@ -191,7 +192,7 @@ int gridFor(const rt_ctx *ctx, uint64_t items, int blocksPerCU) {
 
 // Builds the traversal re-pack from the uploaded model streams and validates
 // every offset the kernels will follow.
-int repackScene(rt_ctx *ctx, std::vector<PackedNode> &nodes, std::vector<PackedTri> &tris, std::vector<ModelDesc> &descs) {
+int repackScene(rt_ctx *ctx, std::vector<PackedNode> &nodes, std::vector<PackedTri> &tris, std::vector<PackedShade> &shade, std::vector<ModelDesc> &descs) {
     const std::vector<float> &info = ctx->host[RT_SLOT_MODEL_INFO];
     const std::vector<float> &mdl = ctx->host[RT_SLOT_MODELS];
     const std::vector<float> &mats = ctx->host[RT_SLOT_MATERIALS];
@@ -287,6 +288,19 @@ int repackScene(rt_ctx *ctx, std::vector<PackedNode> &nodes, std::vector<PackedT
                 }
             }
             tris.push_back(pt);
+            PackedShade ps{};
+            for (int k = 0; k < 3; ++k) {
+                ps.n0[k] = A[3 + k];
+                ps.n1[k] = B[3 + k];
+                ps.n2[k] = C[3 + k];
+            }
+            for (int k = 0; k < 2; ++k) {
+                ps.uv0[k] = A[6 + k];
+                ps.uv1[k] = B[6 + k];
+                ps.uv2[k] = C[6 + k];
+            }
+            ps.hasTextures = hasTextures ? 1 : 0;
+            shade.push_back(ps);
         }
 
         // Inner nodes get consecutive packed indices in original node order.
@@ -767,7 +781,7 @@ void rt_destroy(rt_ctx *ctx) {
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
     for (float *p : ctx->dStream) if (p) hipFree(p);
-    void *owned[] = {ctx->dNodes, ctx->dWNodes, ctx->pb.overflow, ctx->dTris, ctx->dModelDesc, ctx->accumExternal ? nullptr : (void *)ctx->dAccum, ctx->dPartial,
+    void *owned[] = {ctx->dNodes, ctx->dWNodes, ctx->pb.overflow, ctx->dTris, ctx->dShade, ctx->dModelDesc, ctx->accumExternal ? nullptr : (void *)ctx->dAccum, ctx->dPartial,
                      ctx->pb.rays, ctx->pb.hits, ctx->pb.stA, ctx->pb.stB, ctx->pb.neeA, ctx->pb.neeB, ctx->pb.neeC,
                      ctx->pb.qExt[0], ctx->pb.qExt[1], ctx->pb.qShadow, ctx->pb.stages, ctx->pb.counters};
     for (void *p : owned) if (p) hipFree(p);
@@ -801,8 +815,9 @@ int rt_commit_scene(rt_ctx *ctx, int objectCount, int modelsCount, int lightSour
 
     std::vector<PackedNode> nodes;
     std::vector<PackedTri> tris;
+    std::vector<PackedShade> shade;
     std::vector<ModelDesc> descs;
-    int rc = repackScene(ctx, nodes, tris, descs);
+    int rc = repackScene(ctx, nodes, tris, shade, descs);
     if (rc != RT_OK) return rc;
 
     // Raw streams, each padded with 8 zero words so the one-past-the-end reads the
@@ -829,6 +844,8 @@ int rt_commit_scene(rt_ctx *ctx, int objectCount, int modelsCount, int lightSour
     }
     if ((rc = devAlloc(ctx, &ctx->dNodes, nodes.size())) != RT_OK) return rc;
     if ((rc = devAlloc(ctx, &ctx->dTris, tris.size())) != RT_OK) return rc;
+    if ((rc = devAlloc(ctx, &ctx->dShade, shade.size())) != RT_OK) return rc;
+    if (!shade.empty()) RT_HIP(hipMemcpy(ctx->dShade, shade.data(), shade.size() * sizeof(PackedShade), hipMemcpyHostToDevice));
     if ((rc = devAlloc(ctx, &ctx->dModelDesc, descs.size())) != RT_OK) return rc;
     if (!nodes.empty()) RT_HIP(hipMemcpy(ctx->dNodes, nodes.data(), nodes.size() * sizeof(PackedNode), hipMemcpyHostToDevice));
     if (!tris.empty()) RT_HIP(hipMemcpy(ctx->dTris, tris.data(), tris.size() * sizeof(PackedTri), hipMemcpyHostToDevice));
@@ -844,6 +861,7 @@ int rt_commit_scene(rt_ctx *ctx, int objectCount, int modelsCount, int lightSour
     v.nodes = ctx->dNodes;
     v.wnodes = ctx->wideBvh ? ctx->dWNodes : nullptr;
     v.tris = ctx->dTris;
+    v.shade = ctx->dShade;
     v.modelDesc = ctx->dModelDesc;
     v.objectCount = objectCount;
     v.modelsCount = modelsCount;

@@ -51,16 +51,14 @@ __device__ __forceinline__ void orderPair(float &da, int32_t &ca, float &db, int
 // Alpha-cut rejection inside hitTriangle (src/RayScene.cpp:547-577).  Only
 // triangles flagged kTriAlphaTest at commit time come here.  The traversal kernel
 // runs it in a phase of its own, where no node or triangle temporaries are live.
-__device__ __forceinline__ bool alphaCutRejects(const SceneView &sc, const PackedTri &pt, V3 ro, V3 rd, float t) {
-    const ModelDesc &md = sc.modelDesc[pt.model & kTriModelMask];
-    const float *idw = sc.models + md.identBase + pt.ident * kIdentWords;
-    int32_t idx[3] = {f2i(idw[0]), f2i(idw[1]), f2i(idw[2])};
-    TriVerts tv;
-    loadTriVerts(sc, md.vertBase, idx, tv);
+__device__ __forceinline__ bool alphaCutRejects(const SceneView &sc, uint32_t tri, V3 ro, V3 rd, float t) {
+    const PackedTri &pt = sc.tris[tri];
+    const PackedShade &ps = sc.shade[tri];
     const float *m = sc.materials + pt.material * kMaterialWords;
     int baseColor = f2i(m[1]);
     float alphaCut = m[20];
-    V2 uv = cramerUV(tv.p[0], tv.p[1], tv.p[2], tv.uv[0], tv.uv[1], tv.uv[2], ro + t * rd);
+    V2 uv = cramerUV(v3(pt.a[0], pt.a[1], pt.a[2]), v3(pt.ab[0], pt.ab[1], pt.ab[2]), v3(pt.ac[0], pt.ac[1], pt.ac[2]),
+                     v2(ps.uv0[0], ps.uv0[1]), v2(ps.uv1[0], ps.uv1[1]), v2(ps.uv2[0], ps.uv2[1]), ro + t * rd);
     int at = texelOffset(sc, baseColor, uv);
     return sc.textures[at + 3] < alphaCut;
 }
@@ -424,7 +422,7 @@ __global__ __launch_bounds__(kBlock, WIDE ? (ALPHA ? RT_WWIDE_ALPHA : RT_WWIDE)
             const int nPending = __popcll(__ballot(pending));
             if (nPending > 0 && (nPending >= 8 || nPending == nActive)) {
                 if (pending) {
-                    if (!alphaCutRejects(sc, sc.tris[r.pendTri], r.ro, r.rd, r.pendT)) {
+                    if (!alphaCutRejects(sc, r.pendTri, r.ro, r.rd, r.pendT)) {
                         if (!WIDE) r.tModel = r.pendT;
                         r.maxT = r.pendT;
                         r.mBest = r.pendTri;
