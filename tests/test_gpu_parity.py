@@ -568,3 +568,21 @@ def test_unstratified_sampling_branch(backend, name, kw, rpp):
     assert n == frames and samples == W * H * rpp * frames == st["camera_samples"]
     assert np.array_equal(got, want, equal_nan=True), f"{int(np.any(got != want, axis=-1).sum())} differing pixels"
     assert np.array_equal(small, got, equal_nan=True)
+
+
+def test_unstratified_option_is_ignored_by_the_spectral_integrator(backend):
+    """The Spectral main has no `#else` sampling branch (src/RayTracer.cpp:1342-1371)."""
+    W, H = 48, 32
+    scene, cam = _setup(backend, "prism", {}, W, H, 3, 4, capi.RT_TYPE_SPECTRAL)
+    backend.render(first_frame=1, n_frames=2, stride=1)
+    ref, _ = backend.readback()
+    try:
+        backend.set_option(capi.RT_OPT_STRATIFIED, 0)
+        backend.set_frame(cam, scene.sky, capi.RT_TYPE_SPECTRAL)
+        backend.reset_accum()
+        backend.render(first_frame=1, n_frames=2, stride=1)
+        got, _ = backend.readback()
+    finally:
+        backend.set_option(capi.RT_OPT_STRATIFIED, 1)
+        backend.set_frame(cam, scene.sky, capi.RT_TYPE_SPECTRAL)
+    assert np.array_equal(got, ref, equal_nan=True)
