@@ -185,6 +185,12 @@ int rt_set_counters(rt_ctx *ctx, int enabled);
  *                            triangles are hit at the same distance (shared edges, coplanar
  *                            duplicates) the other one may win.  Default 0: the reference's order,
  *                            bit-identical hits.  Rebuilds the derived tree of a committed scene.
+ *                            2: as 1, but the four-wide trees are collapsed from binary trees the
+ *                            library builds itself over each model's triangles (binned
+ *                            surface-area splits) instead of the uploaded median-split trees; the
+ *                            uploaded node section is then only validated.  Same closest hits, same
+ *                            tie caveat, about a third of the node visits and half of the triangle
+ *                            tests of the reference order.
  *   RT_OPT_HERO_WAVELENGTH   1: the Spectral integrator built with HERO_WAVELENGTH_ENABLE 1
  *                            (src/RayTracer.cpp:607, 1257-1280, 1357-1364): every camera sample traces
  *                            four wavelengths, spread over the range from one random offset, along

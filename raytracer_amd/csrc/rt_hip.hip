@@ -67,7 +67,7 @@ struct rt_ctx {
     bool committed = false;
     PackedNode *dNodes = nullptr;
     WideNode *dWNodes = nullptr;    // four-wide tree (wideBvh only)
-    bool wideBvh = false;
+    int wideBvh = 0;                // 0 off, 1 derived from the uploaded trees, 2 the library's own trees
     int wideStackNeed = 0;          // most stack entries a ray can hold in the four-wide tree
     PackedTri *dTris = nullptr;
     PackedShade *dShade = nullptr;
@@ -360,12 +360,154 @@ int repackScene(rt_ctx *ctx, std::vector<PackedNode> &nodes, std::vector<PackedT
     return RT_OK;
 }
 
+// Binary tree over one model's triangles by binned surface-area splits (16 bins per axis on the
+// triangle centres), for RT_OPT_WIDE_BVH = 2.  Nodes are emitted in pre-order through `emit(box,
+// left, right, leafRef, leaf)` with child numbers relative to the model's first node; leaves hold one
+// or two triangles (three where equal centres leave no split).  The model's packed triangle and
+// shading records are permuted into leaf order.  Boxes are the exact bounds of the vertices; the
+// margin the device arithmetic needs is added when they are quantised.
+template <typename Emit>
+bool sahTree(const std::vector<float> &mdl, const ModelDesc &d, std::vector<PackedTri> &tris, std::vector<PackedShade> &shade, Emit emit) {
+    const int T = d.identifiersCount;
+    struct Prim { float box[6]; float centre[3]; };
+    std::vector<Prim> prims((size_t)T);
+    for (int t = 0; t < T; ++t) {
+        const int at = d.identBase + t * kIdentWords;
+        Prim &p = prims[(size_t)t];
+        for (int k = 0; k < 3; ++k) { p.box[k] = INFINITY; p.box[3 + k] = -INFINITY; }
+        for (int c = 0; c < 3; ++c) {
+            const float *v = &mdl[(size_t)d.vertBase + (size_t)f2i(mdl[(size_t)at + c]) * 8];
+            for (int k = 0; k < 3; ++k) {
+                if (!(std::fabs(v[k]) <= 1e15f)) return false;
+                p.box[k] = std::min(p.box[k], v[k]);
+                p.box[3 + k] = std::max(p.box[3 + k], v[k]);
+            }
+        }
+        for (int k = 0; k < 3; ++k) p.centre[k] = 0.5f * p.box[k] + 0.5f * p.box[3 + k];
+    }
+    std::vector<int32_t> order((size_t)T);
+    for (int t = 0; t < T; ++t) order[(size_t)t] = t;
+
+    struct Node { float box[6]; int32_t left, right, lo, hi; };
+    std::vector<Node> nodes;
+    nodes.reserve((size_t)T);
+    auto bounds = [&](int lo, int hi, float *box) {
+        for (int k = 0; k < 3; ++k) { box[k] = INFINITY; box[3 + k] = -INFINITY; }
+        for (int i = lo; i < hi; ++i)
+            for (int k = 0; k < 3; ++k) {
+                box[k] = std::min(box[k], prims[(size_t)order[(size_t)i]].box[k]);
+                box[3 + k] = std::max(box[3 + k], prims[(size_t)order[(size_t)i]].box[3 + k]);
+            }
+    };
+    auto halfArea = [](const float *b) {
+        const double ex = (double)b[3] - b[0], ey = (double)b[4] - b[1], ez = (double)b[5] - b[2];
+        return ex * ey + ey * ez + ez * ex;
+    };
+    // Pre-order with an explicit stack: a node is numbered when it is taken off the stack, its left
+    // subtree follows it directly, and the parent's right link is patched when that child is numbered.
+    struct Todo { int lo, hi, parent; bool isRight; int depth; };
+    std::vector<Todo> todo{{0, T, -1, false, 0}};
+    constexpr int kBins = 16;
+    while (!todo.empty()) {
+        const Todo it = todo.back();
+        todo.pop_back();
+        const int32_t self = (int32_t)nodes.size();
+        nodes.emplace_back();
+        if (it.parent >= 0) (it.isRight ? nodes[(size_t)it.parent].right : nodes[(size_t)it.parent].left) = self;
+        Node n{};
+        bounds(it.lo, it.hi, n.box);
+        n.lo = it.lo;
+        n.hi = it.hi;
+        n.left = n.right = -1;
+        const int count = it.hi - it.lo;
+        int mid = -1;
+        if (count > 2) {
+            float cb[6];
+            for (int k = 0; k < 3; ++k) { cb[k] = INFINITY; cb[3 + k] = -INFINITY; }
+            for (int i = it.lo; i < it.hi; ++i)
+                for (int k = 0; k < 3; ++k) {
+                    cb[k] = std::min(cb[k], prims[(size_t)order[(size_t)i]].centre[k]);
+                    cb[3 + k] = std::max(cb[3 + k], prims[(size_t)order[(size_t)i]].centre[k]);
+                }
+            double bestCost = INFINITY;
+            int bestAxis = -1, bestBin = -1;
+            if (it.depth < 48) {
+                for (int axis = 0; axis < 3; ++axis) {
+                    const double extent = (double)cb[3 + axis] - cb[axis];
+                    if (!(extent > 0.0)) continue;
+                    int counts[kBins] = {0};
+                    float boxes[kBins][6];
+                    for (auto &b : boxes) for (int k = 0; k < 3; ++k) { b[k] = INFINITY; b[3 + k] = -INFINITY; }
+                    for (int i = it.lo; i < it.hi; ++i) {
+                        const Prim &p = prims[(size_t)order[(size_t)i]];
+                        int b = (int)(kBins * (((double)p.centre[axis] - cb[axis]) / extent));
+                        b = std::min(std::max(b, 0), kBins - 1);
+                        counts[b]++;
+                        for (int k = 0; k < 3; ++k) { boxes[b][k] = std::min(boxes[b][k], p.box[k]); boxes[b][3 + k] = std::max(boxes[b][3 + k], p.box[3 + k]); }
+                    }
+                    double rightArea[kBins];
+                    int rightCount[kBins];
+                    float acc[6];
+                    for (int k = 0; k < 3; ++k) { acc[k] = INFINITY; acc[3 + k] = -INFINITY; }
+                    int c = 0;
+                    for (int b = kBins - 1; b > 0; --b) {
+                        for (int k = 0; k < 3; ++k) { acc[k] = std::min(acc[k], boxes[b][k]); acc[3 + k] = std::max(acc[3 + k], boxes[b][3 + k]); }
+                        c += counts[b];
+                        rightArea[b] = c ? halfArea(acc) : 0.0;
+                        rightCount[b] = c;
+                    }
+                    for (int k = 0; k < 3; ++k) { acc[k] = INFINITY; acc[3 + k] = -INFINITY; }
+                    c = 0;
+                    for (int b = 0; b < kBins - 1; ++b) {
+                        for (int k = 0; k < 3; ++k) { acc[k] = std::min(acc[k], boxes[b][k]); acc[3 + k] = std::max(acc[3 + k], boxes[b][3 + k]); }
+                        c += counts[b];
+                        if (c == 0 || rightCount[b + 1] == 0) continue;
+                        const double cost = halfArea(acc) * c + rightArea[b + 1] * rightCount[b + 1];
+                        if (cost < bestCost) { bestCost = cost; bestAxis = axis; bestBin = b; }
+                    }
+                }
+            }
+            if (bestAxis >= 0) {
+                const double extent = (double)cb[3 + bestAxis] - cb[bestAxis];
+                auto first = order.begin() + it.lo, last = order.begin() + it.hi;
+                auto split = std::partition(first, last, [&](int32_t t) {
+                    int b = (int)(kBins * (((double)prims[(size_t)t].centre[bestAxis] - cb[bestAxis]) / extent));
+                    return std::min(std::max(b, 0), kBins - 1) <= bestBin;
+                });
+                mid = (int)(split - order.begin());
+            }
+            if (mid <= it.lo || mid >= it.hi) mid = count > 3 ? it.lo + count / 2 : -1;   // equal centres: halve, or keep three together
+        }
+        nodes[(size_t)self] = n;
+        if (mid > 0) {
+            todo.push_back({mid, it.hi, self, true, it.depth + 1});
+            todo.push_back({it.lo, mid, self, false, it.depth + 1});
+        }
+    }
+    // Records into leaf order, then the nodes.
+    std::vector<PackedTri> newTris((size_t)T);
+    std::vector<PackedShade> newShade((size_t)T);
+    for (int i = 0; i < T; ++i) {
+        newTris[(size_t)i] = tris[(size_t)d.triBase + (size_t)order[(size_t)i]];
+        newShade[(size_t)i] = shade[(size_t)d.triBase + (size_t)order[(size_t)i]];
+    }
+    std::copy(newTris.begin(), newTris.end(), tris.begin() + d.triBase);
+    std::copy(newShade.begin(), newShade.end(), shade.begin() + d.triBase);
+    for (const Node &n : nodes) {
+        const bool leaf = n.left < 0;
+        const int32_t leafRef = leaf ? ~(int32_t)((((uint32_t)(d.triBase + n.lo)) << 2) | (uint32_t)(n.hi - n.lo)) : 0;
+        emit(n.box, n.left, n.right, leafRef, leaf);
+    }
+    return true;
+}
+
 // Four-wide tree of every model, collapsed from the binary tree of the model stream: a node adopts
 // the children of its child with the largest box until it has four (or only leaves are left).
 // `descs` must have passed repackScene; rootRef is redirected to the new tree.
-int buildWideNodes(rt_ctx *ctx, std::vector<ModelDesc> &descs, std::vector<WideNode> &wnodes) {
+int buildWideNodes(rt_ctx *ctx, std::vector<ModelDesc> &descs, std::vector<WideNode> &wnodes, std::vector<PackedTri> &tris, std::vector<PackedShade> &shade) {
     const std::vector<float> &mdl = ctx->host[RT_SLOT_MODELS];
     ctx->wideStackNeed = 0;
+    const bool rebuild = ctx->wideBvh == 2;
 
     // All binary nodes in one array: box, children (indices into it), or the leaf reference.
     struct Bin { float box[6]; int32_t left, right; int32_t leafRef; bool leaf; };
@@ -374,6 +516,27 @@ int buildWideNodes(rt_ctx *ctx, std::vector<ModelDesc> &descs, std::vector<WideN
     double reach = 0.0;
     for (ModelDesc &d : descs) {
         if (d.nodesCount <= 0) continue;
+        if (rebuild && d.identifiersCount > 0) {
+            // The library's own tree over the model's triangles: binned surface-area splits, leaves
+            // of one or two triangles, the packed triangle records reordered into leaf order.
+            const int32_t base = (int32_t)bin.size();
+            if (!sahTree(mdl, d, tris, shade, [&](const float *box, int32_t left, int32_t right, int32_t leafRef, bool leaf) {
+                    Bin b{};
+                    for (int k = 0; k < 6; ++k) b.box[k] = box[k];
+                    b.left = leaf ? -1 : base + left;
+                    b.right = leaf ? -1 : base + right;
+                    b.leafRef = leafRef;
+                    b.leaf = leaf;
+                    bin.push_back(b);
+                })) return RT_ERR_SCENE;
+            if (bin[(size_t)base].leaf) {
+                d.rootRef = bin[(size_t)base].leafRef;
+                continue;
+            }
+            roots.push_back({base, &d});
+            for (int k = 0; k < 6; ++k) reach = std::max(reach, (double)std::fabs(bin[(size_t)base].box[k]));
+            continue;
+        }
         const int32_t base = (int32_t)bin.size();
         bin.resize(bin.size() + (size_t)d.nodesCount);
         for (int n = 0; n < d.nodesCount; ++n) {
@@ -763,7 +926,7 @@ int rt_create(rt_ctx **out, int device) {
         if (v > 0) ctx->maxPaths = (uint32_t)std::min<long>(v, 1l << 30);
     }
     if (const char *env = std::getenv("RT_TILE_MAJOR")) ctx->planesInner = std::atoi(env) != 0;
-    if (const char *env = std::getenv("RT_WIDE_BVH")) ctx->wideBvh = std::atoi(env) != 0;
+    if (const char *env = std::getenv("RT_WIDE_BVH")) ctx->wideBvh = std::min(std::max(std::atoi(env), 0), 2);
     if (const char *env = std::getenv("RT_INNER_SHARE")) {
         int v = std::atoi(env);
         if (v >= 1 && v <= 64) ctx->innerShare = v;
@@ -831,7 +994,7 @@ int rt_commit_scene(rt_ctx *ctx, int objectCount, int modelsCount, int lightSour
     }
     std::vector<WideNode> wnodes;
     if (ctx->wideBvh) {
-        if ((rc = buildWideNodes(ctx, descs, wnodes)) != RT_OK) return rc;
+        if ((rc = buildWideNodes(ctx, descs, wnodes, tris, shade)) != RT_OK) return rc;
         if ((rc = devAlloc(ctx, &ctx->dWNodes, wnodes.size())) != RT_OK) return rc;
         if (!wnodes.empty()) RT_HIP(hipMemcpy(ctx->dWNodes, wnodes.data(), wnodes.size() * sizeof(WideNode), hipMemcpyHostToDevice));
         // Stack entries that do not fit in LDS: one column per lane of every wave the grid can hold.
@@ -1201,8 +1364,9 @@ int rt_set_option(rt_ctx *ctx, int option, int value) {
             ctx->maxPaths = (uint32_t)value;
             return RT_OK;
         case RT_OPT_WIDE_BVH:
-            if (ctx->wideBvh == (value != 0)) return RT_OK;
-            ctx->wideBvh = value != 0;
+            if (value < 0 || value > 2) return RT_ERR_INVALID;
+            if (ctx->wideBvh == value) return RT_OK;
+            ctx->wideBvh = value;
             if (!ctx->committed) return RT_OK;
             ctx->dirty = true;   // the derived tree belongs to the committed scene: rebuild it now
             return rt_commit_scene(ctx, ctx->objectCount, ctx->modelsCount, ctx->lightSourcesCount);

@@ -1,6 +1,7 @@
-"""GPU: the opt-in four-wide tree (RT_OPT_WIDE_BVH) against the CPU checker.
+"""GPU: the opt-in four-wide trees (RT_OPT_WIDE_BVH 1 and 2) against the CPU checker.
 
-The wide tree is derived from the uploaded binary tree and finds every ray's closest hit, but not
+The wide tree is derived from the uploaded binary tree (1) or from a tree the library builds itself
+over the same triangles (2) and finds every ray's closest hit, but not
 in the visiting order of hitModel (src/RayScene.cpp:681-736): among triangles hit at the same
 distance the other one may win.  Bars:
   * primary-hit ids equal to the checker's wherever no second triangle lies at the same t
@@ -31,10 +32,12 @@ SCENES = [
 ]
 
 
-@pytest.fixture(scope="module")
-def wide():
+@pytest.fixture(scope="module", params=[1, 2], ids=["from_uploaded_trees", "library_built_trees"])
+def wide(request):
+    """1: four-wide trees collapsed from the uploaded binary trees; 2: from trees the library builds itself."""
     b = capi.Backend(0)
-    b.set_option(capi.RT_OPT_WIDE_BVH, 1)
+    b.set_option(capi.RT_OPT_WIDE_BVH, request.param)
+    b.wide_mode = request.param
     yield b
     b.close()
 
@@ -102,7 +105,8 @@ def test_wide_deep_stack_spills_to_memory(wide):
         deepest = wide.stats()["max_stack"]
     finally:
         wide.set_counters(False)
-    assert deepest > 16, f"deepest stack {deepest}: the scene does not reach the in-memory part"
+    if wide.wide_mode == 1:   # the library's own trees separate the soup better and may stay on chip
+        assert deepest > 16, f"deepest stack {deepest}: the scene does not reach the in-memory part"
     want, _ = OracleScene(scene).render(cam, capi.RT_TYPE_RGB, 1, 1, 1)
     assert rel_rmse(got, want) <= 1e-4
 
@@ -119,13 +123,21 @@ def test_wide_option_rebuilds_committed_scene():
         b.reset_accum()
         b.render(1, 2, 1)
         got, _ = b.readback()
+        b.set_option(capi.RT_OPT_WIDE_BVH, 2)
+        b.reset_accum()
+        b.render(1, 2, 1)
+        own, _ = b.readback()
         b.set_option(capi.RT_OPT_WIDE_BVH, 0)
         b.reset_accum()
         b.render(1, 2, 1)
         back, _ = b.readback()
+        assert b.set_option(capi.RT_OPT_WIDE_BVH, 0) is None
+        with pytest.raises(capi.RtError):
+            b.set_option(capi.RT_OPT_WIDE_BVH, 3)
     finally:
         b.close()
     assert rel_rmse(got, ref) <= 1e-4
+    assert rel_rmse(own, ref) <= 1e-4
     assert np.array_equal(back, ref)
 
 

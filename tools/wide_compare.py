@@ -21,12 +21,13 @@ CASES = [
     ("fuzz", dict(seed=11), 160, 120, capi.RT_TYPE_SPECTRAL),
 ]
 
+MODE = int(sys.argv[1]) if len(sys.argv) > 1 else 1      # 1: derived from the uploaded trees, 2: the library's own trees
 bad = 0
 for name, kw, W, H, rtype in CASES:
     scene = capi.Scene(name, **kw)
     cam = capi.make_camera(width=W, height=H, bounces=4, ray_per_pixel=4)
     out = {}
-    for wide in (0, 1):
+    for wide in (0, MODE):
         be = capi.Backend(0)
         be.set_option(capi.RT_OPT_WIDE_BVH, wide)
         be.upload_scene(scene)
@@ -40,7 +41,7 @@ for name, kw, W, H, rtype in CASES:
         out[wide] = (prim, img, be.stats())
         be.close()
     (m0, i0, t0, u0, v0), img0, st0 = out[0]
-    (m1, i1, t1, u1, v1), img1, st1 = out[1]
+    (m1, i1, t1, u1, v1), img1, st1 = out[MODE]
     idDiff = (m0 != m1) | (i0 != i1)
     tDiff = np.abs(t0 - t1) > 1e-5 * np.maximum(np.abs(t0), 1e-30)
     pixDiff = np.any(img0 != img1, axis=-1)
