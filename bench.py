@@ -86,10 +86,10 @@ def main():
 
     be = capi.Backend(local_rank)
     if args.wide:
-        be.set_option(capi.RT_OPT_WIDE_BVH, 1)
+        be.set_option(capi.RT_OPT_WIDE_BVH, args.wide)
     if args.hero:
         be.set_option(capi.RT_OPT_HERO_WAVELENGTH, 1)
-    wide = args.wide or os.environ.get("RT_WIDE_BVH", "0") not in ("", "0")
+    wide = args.wide or int(os.environ.get("RT_WIDE_BVH", "0") or 0)
     be.upload_scene(scene)
     be.resize(args.width, args.height)
     # The sum buffer is a torch tensor so RCCL can reduce it in place.
