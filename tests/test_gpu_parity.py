@@ -389,7 +389,7 @@ def test_sah_tree_mode_matches_checker(backend, rtype):
     assert np.array_equal(got, want, equal_nan=True)
 
 
-@pytest.mark.parametrize("flags", [[], ["--wide"]])
+@pytest.mark.parametrize("flags", [[], ["--wide"], ["--wide2"]])
 def test_cpp_example_program_renders_the_same_picture(tmp_path, flags):
     """examples/rt_render drives the C++ host API the way the reference's main() does; its PNG must
     equal the display pass of the same scene rendered through the C ABI from here (also when the
