@@ -100,6 +100,7 @@ struct rt_ctx {
     uint32_t tileOffset = 0, tileStride = 1;
     bool planesInner = true;   // tile-major path order inside a batch
     int refillLanes = 32;   // idle lanes that trigger a refill for stages > 0
+    bool refillChosen = false;   // set through the option or the environment
     int innerShare = 48;    // inner phase runs while >= innerShare/64 of the active lanes sit on inner nodes
 
     // RCCL communicator of rt_comm_init (library loaded on first use), one rank per context.
@@ -724,7 +725,9 @@ void launchTrace(rt_ctx *ctx, int extParity, int stage) {
     hipEvent_t e0 = takeEvent(ctx), e1 = takeEvent(ctx);
     if (e0) hipEventRecord(e0, ctx->stream);
     // Camera rays (stage 0) stay in 64-ray packets; later stages refill idle lanes.
-    const int refill = stage == 0 ? 64 : ctx->refillLanes;
+    // The library-built wide trees make rays short; they run best with a slightly later refill
+    // (40 idle lanes: +1.5 %) unless the caller chose a value.
+    const int refill = stage == 0 ? 64 : (!ctx->refillChosen && ctx->wideBvh == 2) ? 40 : ctx->refillLanes;
     // Kernel variant: visit counting, LDS stack depth (24 entries let 6 blocks share a
     // CU's LDS instead of 5), alpha-cut support only when some triangle needs it.
     using TraceFn = void (*)(SceneView, PathBuffers, int, int, int, int);
@@ -933,7 +936,7 @@ int rt_create(rt_ctx **out, int device) {
     }
     if (const char *env = std::getenv("RT_REFILL_LANES")) {
         int v = std::atoi(env);
-        if (v >= 1 && v <= 64) ctx->refillLanes = v;
+        if (v >= 1 && v <= 64) { ctx->refillLanes = v; ctx->refillChosen = true; }
     }
     *out = ctx;
     return RT_OK;
@@ -1334,6 +1337,7 @@ int rt_set_option(rt_ctx *ctx, int option, int value) {
         case RT_OPT_REFILL_LANES:
             if (value < 1 || value > 64) return RT_ERR_INVALID;
             ctx->refillLanes = value;
+            ctx->refillChosen = true;
             return RT_OK;
         case RT_OPT_INNER_SHARE:
             if (value < 1 || value > 64) return RT_ERR_INVALID;
