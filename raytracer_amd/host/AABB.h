@@ -10,5 +10,6 @@ struct AABB {
     // double and narrowed to f32, so repeated unions grow the box cumulatively.
     AABB(const AABB &a, const AABB &b);
 
-    glm::vec3 min, max;
+    glm::vec3 min;   // lower corner (padded)
+    glm::vec3 max;   // upper corner (padded)
 };

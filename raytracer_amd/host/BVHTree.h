@@ -10,16 +10,14 @@ struct BVHNode {
     AABB box;
     // Inner node: child node indices.  Leaf: [leftIndex, rightIndex) into the
     // model's (re-ordered) identifier list.
-    i32 leftIndex = -1, rightIndex = -1;
+    i32 leftIndex = -1;
+    i32 rightIndex = -1;
     bool isLeaf = false;
-
-    BVHNode() = default;
 };
 
 struct Model;
-class BVHTree {
-    std::vector<BVHNode> m_nodes;
 
+class BVHTree {
 public:
     // Reference: the reference's median split, the only mode whose images are the reference's.
     // SAH: binned surface-area-heuristic splits (no reference counterpart; opt-in).  Same node
@@ -36,5 +34,9 @@ public:
     explicit BVHTree(Model &model);
     BVHTree(Model &model, Mode mode);
 
+    // Pre-order: node 0 is the root, children come after their parent.
     const std::vector<BVHNode> &getNodes() const { return m_nodes; }
+
+private:
+    std::vector<BVHNode> m_nodes;
 };

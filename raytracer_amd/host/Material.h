@@ -11,32 +11,26 @@ using GVec3 = glm::vec<3, f32, glm::packed>;
 // Texture references: -1 = none.  After RayScene::addModel they hold the float
 // offset of the texture header inside the scene-wide texture stream.
 struct MaterialTexture {
-    i32 normalTexture = -1;
-    i32 baseColorTexture = -1;
-    i32 metallicRoughnessTexture = -1;
-    i32 emissiveTexture = -1;
-    i32 transmissionTexture = -1;
-    i32 occlusionTexture = -1;
+    i32 normalTexture = -1, baseColorTexture = -1, metallicRoughnessTexture = -1;
+    i32 emissiveTexture = -1, transmissionTexture = -1, occlusionTexture = -1;
 };
 
 struct Material : public gpu::Serializable {
+    // Emission: colour and a scale; a material emits when both are non-zero.
     GVec3 emissionColor = {0, 0, 0};
     f32 emissionStrength = 0;
 
+    // Disney-style surface terms.
     GVec3 albedo = {1, 1, 1};
-    f32 subsurface = 0;
-    f32 roughness = 1.0f;
-    f32 metallic = 0;
-    f32 specular = 0.5f;
-    f32 specularTint = 0;
+    f32 subsurface = 0, roughness = 1.0f, metallic = 0;
+    f32 specular = 0.5f, specularTint = 0;
 
-    f32 transmission = 0;
-    f32 ior = 1.5f;
+    // Refraction: share of transmitted light and index of refraction.
+    f32 transmission = 0, ior = 1.5f;
 
+    // Texture modifiers: alpha below alphaCut is a miss; normalScale < 0 means "no normal map".
     f32 alphaCut = 0;
-
-    f32 normalScale = -1;
-    f32 occlusionStrength = 1.0f;
+    f32 normalScale = -1, occlusionStrength = 1.0f;
 
     MaterialTexture texture;
 

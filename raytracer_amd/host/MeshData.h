@@ -9,20 +9,22 @@
 #include <vector>
 
 struct MeshData {
+    // 8 words on the wire: position, normal, texture coordinate.
     struct Vertex {
-        glm::vec3 position;
-        glm::vec3 normal;
+        glm::vec3 position, normal;
         glm::vec2 uv;
     };
     std::vector<Vertex> vertices;
 
     // One triangle: three vertex indices + material; 5 words on the wire.
     struct Identifier : public gpu::Serializable {
-        glm::ivec3 index;
-        i32 materialIndex = 0;
-        bool hasTextures = false;
+        glm::ivec3 index;             // into `vertices`
+        i32 materialIndex = 0;        // into `materials` until the scene rebases it
+        bool hasTextures = false;     // the material has at least one texture
         void serialize(gpu::Buffer &out) const override;
     };
+
+    // The model's triangles, the materials they name, and the textures those name.
     std::vector<Identifier> identifiers;
     std::vector<Material> materials;
 
@@ -31,7 +33,9 @@ struct MeshData {
 
     // Texel data already converted to f32; header is 5 words on the wire.
     struct Texture : public gpu::Serializable {
-        i32 width = 0, height = 0, channels = 0, channelSize = 1, wrapS = 10497, wrapT = 10497;
+        i32 width = 0, height = 0, channels = 0;
+        i32 channelSize = 1;                    // bytes per channel in the source image
+        i32 wrapS = 10497, wrapT = 10497;       // glTF sampler codes; 10497 = repeat
         std::vector<f32> data;
         void serialize(gpu::Buffer &out) const override;
     };

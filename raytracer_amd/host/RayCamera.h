@@ -1,28 +1,37 @@
 // Pinhole camera parameters fed to the ray generator (reference src/RayCamera.h:9-29).
 #pragma once
 
-#include "glm/glm.hpp"
-#include "util.h"
 #include <cmath>
 
+#include "glm/glm.hpp"
+#include "util.h"
+
 struct RayCamera {
+    // Where the camera stands, and where it looks: angles in degrees.  yaw = 90 looks down +z with
+    // +x to the right.
     glm::vec3 position = {0, 0, 0};
-    f32 yaw = 90, pitch = 0, fov = 45;  // degrees
+    f32 yaw = 90;
+    f32 pitch = 0;
+    f32 fov = 45;   // vertical field of view
 
-    glm::vec3 up = glm::vec3(0, 1, 0), right = glm::vec3(1, 0, 0), forward = glm::vec3(0, 0, 1);
+    // Orthonormal frame derived from the angles by updateDirection().
+    glm::vec3 up = glm::vec3(0, 1, 0);
+    glm::vec3 right = glm::vec3(1, 0, 0);
+    glm::vec3 forward = glm::vec3(0, 0, 1);
 
+    // Image size in pixels; path length and samples per pixel per frame (the integrators take
+    // floor(sqrt(rayPerPixel))^2 stratified samples).
     glm::ivec2 resolution = {1024, 1024};
-    i32 bounces = 5, rayPerPixel = 1;
+    i32 bounces = 5;
+    i32 rayPerPixel = 1;
 
-    // Rebuilds forward/right/up from yaw and pitch; yaw = 90 looks down +z
-    // with +x to the right (the x term uses 180 + yaw).
+    // Rebuilds forward/right/up from yaw and pitch (the x term uses 180 + yaw).
     void updateDirection() {
-        const f32 cp = std::cos(glm::radians(pitch));
-        glm::vec3 dir;
-        dir.x = std::cos(glm::radians(180 + yaw)) * cp;
-        dir.y = std::sin(glm::radians(pitch));
-        dir.z = std::sin(glm::radians(yaw)) * cp;
-        forward = glm::normalize(dir);
+        const f32 cosPitch = std::cos(glm::radians(pitch));
+        const glm::vec3 look(std::cos(glm::radians(180 + yaw)) * cosPitch,
+                             std::sin(glm::radians(pitch)),
+                             std::sin(glm::radians(yaw)) * cosPitch);
+        forward = glm::normalize(look);
         right = glm::normalize(-glm::cross(forward, glm::vec3(0, 1, 0)));
         up = glm::cross(-right, forward);
     }

@@ -7,11 +7,6 @@
 #include "RayTracer.h"
 
 class RayEngine {
-private:
-    RayCamera m_camera;
-    RayScene m_rayScene;
-    RayTracer m_rayTracer;
-
 public:
     RayEngine() = default;
 
@@ -24,4 +19,9 @@ public:
     RayScene &getScene() { return m_rayScene; }
     RayTracer &getRayTracer() { return m_rayTracer; }
     RayCamera &getCamera() { return m_camera; }
+
+private:
+    RayCamera m_camera;
+    RayScene m_rayScene;
+    RayTracer m_rayTracer;
 };

@@ -20,28 +20,17 @@ const std::vector<f32> &wordsOf(const gpu::Storage &s) {
 
 void RayScene::initialize(rt_ctx *backend) {
     m_backend = backend;
-    primitiveBuffer = std::make_unique<gpu::FloatBuffer>();
-    modelBuffer = std::make_unique<gpu::FloatBuffer>();
-    modelInfoBuffer = std::make_unique<gpu::FloatBuffer>();
-    textureBuffer = std::make_unique<gpu::FloatBuffer>();
-    materialBuffer = std::make_unique<gpu::FloatBuffer>();
-
-    primitiveGPUStorage = makeStorage(backend, RT_SLOT_OBJECTS);
-    materialGPUStorage = makeStorage(backend, RT_SLOT_MATERIALS);
-    modelInfoGPUStorage = makeStorage(backend, RT_SLOT_MODEL_INFO);
-    modelGPUStorage = makeStorage(backend, RT_SLOT_MODELS);
-    textureGPUStorage = makeStorage(backend, RT_SLOT_TEXTURES);
+    for (int slot = RT_SLOT_OBJECTS; slot <= RT_SLOT_TEXTURES; ++slot) {
+        m_streams[slot].words = std::make_unique<gpu::FloatBuffer>();
+        m_streams[slot].storage = makeStorage(backend, slot);
+    }
 
     // Material 0 is the default material (reference src/RayScene.cpp:25-27).
     m_materials.push_back(Material());
 }
 
 void RayScene::bind() const {
-    primitiveGPUStorage->bindToUnit(RT_SLOT_OBJECTS);
-    materialGPUStorage->bindToUnit(RT_SLOT_MATERIALS);
-    modelInfoGPUStorage->bindToUnit(RT_SLOT_MODEL_INFO);
-    modelGPUStorage->bindToUnit(RT_SLOT_MODELS);
-    textureGPUStorage->bindToUnit(RT_SLOT_TEXTURES);
+    for (int slot = RT_SLOT_OBJECTS; slot <= RT_SLOT_TEXTURES; ++slot) m_streams[slot].storage->bindToUnit(slot);
     if (m_backend != nullptr) {
         int rc = rt_commit_scene(m_backend, static_cast<int>(getObjectsCount()), static_cast<int>(getModelsCount()), lightSourcesCount);
         ASSERT(rc == RT_OK);
@@ -51,30 +40,30 @@ void RayScene::bind() const {
 // Stream order and layouts follow reference src/RayScene.cpp:54-101.
 void RayScene::submit() {
     for (const auto &prim : m_traceableObjects) {
-        primitiveBuffer->push(static_cast<i32>(prim->getType()));
-        primitiveBuffer->push(static_cast<i32>(prim->getMaterialIndex()));
-        prim->serialize(*primitiveBuffer);
+        m_streams[RT_SLOT_OBJECTS].words->push(static_cast<i32>(prim->getType()));
+        m_streams[RT_SLOT_OBJECTS].words->push(static_cast<i32>(prim->getMaterialIndex()));
+        prim->serialize(*m_streams[RT_SLOT_OBJECTS].words);
     }
-    primitiveGPUStorage->upload(*primitiveBuffer);
+    m_streams[RT_SLOT_OBJECTS].storage->upload(*m_streams[RT_SLOT_OBJECTS].words);
 
     auto emitModel = [this](const Model &model) {
-        model.info.serialize(*modelInfoBuffer);
+        model.info.serialize(*m_streams[RT_SLOT_MODEL_INFO].words);
         // 4th info word: where this model's blob starts, in words.
-        modelInfoBuffer->push(static_cast<i32>(modelBuffer->size() / sizeof(f32)));
-        model.serialize(*modelBuffer);
+        m_streams[RT_SLOT_MODEL_INFO].words->push(static_cast<i32>(m_streams[RT_SLOT_MODELS].words->size() / sizeof(f32)));
+        model.serialize(*m_streams[RT_SLOT_MODELS].words);
     };
     for (i32 key : lightSourcesMark) emitModel(*m_modelObjects[key]);
     for (i32 i = 0; i < static_cast<i32>(m_modelObjects.size()); ++i)
         if (lightSourcesMark.find(i) == lightSourcesMark.end()) emitModel(*m_modelObjects[i]);
-    modelGPUStorage->upload(*modelBuffer);
-    modelInfoGPUStorage->upload(*modelInfoBuffer);
+    m_streams[RT_SLOT_MODELS].storage->upload(*m_streams[RT_SLOT_MODELS].words);
+    m_streams[RT_SLOT_MODEL_INFO].storage->upload(*m_streams[RT_SLOT_MODEL_INFO].words);
 
     for (const auto &model : m_modelObjects)
-        for (const auto &tex : model->meshData.textures) tex.serialize(*textureBuffer);
-    textureGPUStorage->upload(*textureBuffer);
+        for (const auto &tex : model->meshData.textures) tex.serialize(*m_streams[RT_SLOT_TEXTURES].words);
+    m_streams[RT_SLOT_TEXTURES].storage->upload(*m_streams[RT_SLOT_TEXTURES].words);
 
-    for (const auto &mat : m_materials) mat.serialize(*materialBuffer);
-    materialGPUStorage->upload(*materialBuffer);
+    for (const auto &mat : m_materials) mat.serialize(*m_streams[RT_SLOT_MATERIALS].words);
+    m_streams[RT_SLOT_MATERIALS].storage->upload(*m_streams[RT_SLOT_MATERIALS].words);
 }
 
 void RayScene::setSkyColor(glm::vec3 skyColor) {
@@ -140,11 +129,7 @@ void RayScene::addObject(const TraceableObject &obj, int materialIndex) {
 std::string RayScene::genShaderCode() { return "hip:gfx950"; }
 
 const std::vector<f32> &RayScene::streamWords(int slot) const {
-    switch (slot) {
-        case RT_SLOT_OBJECTS: return wordsOf(*primitiveGPUStorage);
-        case RT_SLOT_MATERIALS: return wordsOf(*materialGPUStorage);
-        case RT_SLOT_MODEL_INFO: return wordsOf(*modelInfoGPUStorage);
-        case RT_SLOT_MODELS: return wordsOf(*modelGPUStorage);
-        default: return wordsOf(*textureGPUStorage);
-    }
+    // Slots outside 1..5 read the texture stream.
+    const int s = (slot >= RT_SLOT_OBJECTS && slot <= RT_SLOT_TEXTURES) ? slot : RT_SLOT_TEXTURES;
+    return wordsOf(*m_streams[s].storage);
 }

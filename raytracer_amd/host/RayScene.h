@@ -21,23 +21,17 @@ private:
     glm::vec3 m_skyColor = {0.5f, 0.7f, 1.0f};
     glm::vec3 m_linearSkyColor = glm::pow(m_skyColor, glm::vec3(2.2f));
 
+    // One serialised stream per backend slot (RT_SLOT_* 1..5; entry 0 unused): the words being
+    // collected and the storage object that receives them at submit().
+    struct Stream {
+        std::unique_ptr<gpu::Buffer> words;
+        std::unique_ptr<gpu::Storage> storage;
+    };
+    Stream m_streams[6];
+
     std::vector<Material> m_materials;
-    std::unique_ptr<gpu::Buffer> materialBuffer;
-    std::unique_ptr<gpu::Storage> materialGPUStorage;
-
     std::vector<std::unique_ptr<TraceableObject>> m_traceableObjects;
-    std::unique_ptr<gpu::Buffer> primitiveBuffer;
-    std::unique_ptr<gpu::Storage> primitiveGPUStorage;
-
     std::vector<std::unique_ptr<Model>> m_modelObjects;
-    std::unique_ptr<gpu::Buffer> modelBuffer;
-    std::unique_ptr<gpu::Storage> modelGPUStorage;
-
-    std::unique_ptr<gpu::Buffer> modelInfoBuffer;
-    std::unique_ptr<gpu::Storage> modelInfoGPUStorage;
-
-    std::unique_ptr<gpu::Buffer> textureBuffer;
-    std::unique_ptr<gpu::Storage> textureGPUStorage;
 
     // Models that carry emissive triangles; they are serialised FIRST, in this
     // container's iteration order (the light sampler indexes them 0..count-1).
