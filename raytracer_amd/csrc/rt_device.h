@@ -223,6 +223,59 @@ RT_FN V3 triangleNormal(V3 n0, V3 n1, V3 n2, V3 geometric, float u, float v) {
     return normalize(geometric);
 }
 
+// Texture part of hitModels (src/RayScene.cpp:763-844): base colour, metallic-roughness, normal map,
+// emissive, transmission and occlusion textures modify the material and the shading normal.
+// (Inline: as a call it saves 6-12 registers, not enough for another wave, and costs 144 B of scratch.)
+RT_FN void applyTextures(const SceneView &sc, HitInfoD &info, V3 rd, V3 vertexA, V3 edgeAB, V3 edgeAC, V2 uv0, V2 uv1, V2 uv2) {
+    V2 uv = cramerUV(vertexA, edgeAB, edgeAC, uv0, uv1, uv2, info.point);
+    MaterialD &m = info.mat;
+    if (m.baseColorTexture != -1) {
+        int at = texelOffset(sc, m.baseColorTexture, uv);
+        m.albedo = v3(srgbToLinear(sc.textures[at]), srgbToLinear(sc.textures[at + 1]), srgbToLinear(sc.textures[at + 2]));
+        m.transmission *= 1.0f - sc.textures[at + 3];
+    }
+    if (m.metallicRoughnessTexture != -1) {
+        int at = texelOffset(sc, m.metallicRoughnessTexture, uv);
+        m.roughness *= sc.textures[at + 1];
+        m.metallic *= sc.textures[at + 2];
+    }
+    if (m.normalTexture != -1) {
+        // Tangent frame from the triangle's UVs (src/RayScene.cpp:597-621); the
+        // normal map is skipped when they do not define one.
+        V2 d1 = uv1 - uv0, d2 = uv2 - uv0;
+        float uvDet = d1.x * d2.y - d2.x * d1.y;
+        if (abs_(uvDet) > kMinDenominator) {
+            float f = 1.0f / uvDet;
+            V3 tangent = v3(f * (d2.y * edgeAB.x - d1.y * edgeAC.x), f * (d2.y * edgeAB.y - d1.y * edgeAC.y),
+                            f * (d2.y * edgeAB.z - d1.y * edgeAC.z));
+            tangent = tangent - dot(tangent, info.normal) * info.normal;
+            if (length(tangent) > kMinDenominator) {
+                tangent = normalize(tangent);
+                V3 bitangent = cross(info.normal, tangent);
+                int at = texelOffset(sc, m.normalTexture, uv);
+                V3 tn = ld3(sc.textures, at) * 2.0f - v3s(1.0f);
+                tn.x *= m.normalScale;
+                tn.y *= m.normalScale;
+                tn = normalize(tn);
+                info.normal = normalize(tangent * tn.x + bitangent * tn.y + info.normal * tn.z);
+                info.front_face = dot(rd, info.normal) < 0.0f;
+            }
+        }
+    }
+    if (m.emissiveTexture != -1) {
+        int at = texelOffset(sc, m.emissiveTexture, uv);
+        m.emissionColor = m.emissionColor * ld3(sc.textures, at);
+    }
+    if (m.transmissionTexture != -1) {
+        int at = texelOffset(sc, m.transmissionTexture, uv);
+        m.transmission *= sc.textures[at];
+    }
+    if (m.occlusionTexture != -1) {
+        int at = texelOffset(sc, m.occlusionTexture, uv);
+        m.transmission *= 1.0f - (1.0f - sc.textures[at]) * (1.0f - m.occlusionStrength);
+    }
+}
+
 // Rebuilds the full HitInfo of a recorded hit.  The record must not be a miss.
 RT_FN HitInfoD resolveHit(const SceneView &sc, V3 ro, V3 rd, const HitRec &h) {
     HitInfoD info;
@@ -279,55 +332,7 @@ RT_FN HitInfoD resolveHit(const SceneView &sc, V3 ro, V3 rd, const HitRec &h) {
     info.modelLightCounts = md.lightSourcesCount;
     info.mat = loadMaterial(sc, materialIndex);
 
-    if (hasTextures && (h.id & kNoTexBit) == 0u) {                 // src/RayScene.cpp:763-844
-        V2 uv = cramerUV(vertexA, edgeAB, edgeAC, uv0, uv1, uv2, info.point);
-        MaterialD &m = info.mat;
-        if (m.baseColorTexture != -1) {
-            int at = texelOffset(sc, m.baseColorTexture, uv);
-            m.albedo = v3(srgbToLinear(sc.textures[at]), srgbToLinear(sc.textures[at + 1]), srgbToLinear(sc.textures[at + 2]));
-            m.transmission *= 1.0f - sc.textures[at + 3];
-        }
-        if (m.metallicRoughnessTexture != -1) {
-            int at = texelOffset(sc, m.metallicRoughnessTexture, uv);
-            m.roughness *= sc.textures[at + 1];
-            m.metallic *= sc.textures[at + 2];
-        }
-        if (m.normalTexture != -1) {
-            // Tangent frame from the triangle's UVs (src/RayScene.cpp:597-621); the
-            // normal map is skipped when they do not define one.
-            V2 d1 = uv1 - uv0, d2 = uv2 - uv0;
-            float uvDet = d1.x * d2.y - d2.x * d1.y;
-            if (abs_(uvDet) > kMinDenominator) {
-                float f = 1.0f / uvDet;
-                V3 tangent = v3(f * (d2.y * edgeAB.x - d1.y * edgeAC.x), f * (d2.y * edgeAB.y - d1.y * edgeAC.y),
-                                f * (d2.y * edgeAB.z - d1.y * edgeAC.z));
-                tangent = tangent - dot(tangent, info.normal) * info.normal;
-                if (length(tangent) > kMinDenominator) {
-                    tangent = normalize(tangent);
-                    V3 bitangent = cross(info.normal, tangent);
-                    int at = texelOffset(sc, m.normalTexture, uv);
-                    V3 tn = ld3(sc.textures, at) * 2.0f - v3s(1.0f);
-                    tn.x *= m.normalScale;
-                    tn.y *= m.normalScale;
-                    tn = normalize(tn);
-                    info.normal = normalize(tangent * tn.x + bitangent * tn.y + info.normal * tn.z);
-                    info.front_face = dot(rd, info.normal) < 0.0f;
-                }
-            }
-        }
-        if (m.emissiveTexture != -1) {
-            int at = texelOffset(sc, m.emissiveTexture, uv);
-            m.emissionColor = m.emissionColor * ld3(sc.textures, at);
-        }
-        if (m.transmissionTexture != -1) {
-            int at = texelOffset(sc, m.transmissionTexture, uv);
-            m.transmission *= sc.textures[at];
-        }
-        if (m.occlusionTexture != -1) {
-            int at = texelOffset(sc, m.occlusionTexture, uv);
-            m.transmission *= 1.0f - (1.0f - sc.textures[at]) * (1.0f - m.occlusionStrength);
-        }
-    }
+    if (hasTextures && (h.id & kNoTexBit) == 0u) applyTextures(sc, info, rd, vertexA, edgeAB, edgeAC, uv0, uv1, uv2);   // src/RayScene.cpp:763
     return info;
 }
 
