@@ -41,8 +41,8 @@ def parse():
     ap.add_argument("--tex-size", type=int, default=0, help="texture edge of the textured scenes (0 = scene default)")
     ap.add_argument("--bvh", choices=["reference", "sah"], default="reference",
                     help="tree builder: the reference's median split (default; the only mode whose traversal is the reference's) or the opt-in SAH build")
-    ap.add_argument("--wide", type=int, nargs="?", const=1, default=0, choices=[0, 1, 2],
-                    help="opt-in four-wide trees (RT_OPT_WIDE_BVH): closest hits, not the reference's visiting order; 1 = from the uploaded trees, 2 = the library's own SAH trees")
+    ap.add_argument("--wide", type=int, nargs="?", const=1, default=0, choices=[0, 1, 2, 3],
+                    help="opt-in four-wide trees (RT_OPT_WIDE_BVH): closest hits, not the reference's visiting order; 1 = from the uploaded trees, 2 = the library's own SAH trees, 3 = as 2 with distance ties re-traced in the reference's order")
     ap.add_argument("--scene", default="cornell_knot")
     ap.add_argument("--spectral", action="store_true")
     ap.add_argument("--hero", action="store_true", help="Spectral with four wavelengths per camera sample (the reference's HERO_WAVELENGTH_ENABLE 1)")
@@ -188,7 +188,7 @@ def main():
                 "workload": f"{args.scene} ({'procedural dragon-class mesh, ' if 'knot' in args.scene else ''}{triangles} triangles in {scene.models_count} models), "
                             f"{args.width}x{args.height}, {args.spp} spp per {'image' if tile_split else 'GPU'} per step, primary+{args.bounces} bounces, "
                             f"{'Spectral' if args.spectral else 'RGB'} NEE+MIS" + (", hero-wavelength mode (4 wavelengths per camera sample)" if args.hero else "") + (", opt-in SAH trees (not the reference's traversal order)" if args.bvh == "sah" else "")
-                            + (", opt-in four-wide trees" + (" built by the library (SAH)" if wide == 2 else "") + " (closest hits, not the reference's traversal order)" if wide else ""),
+                            + (", opt-in four-wide trees" + (" built by the library (SAH)" if wide >= 2 else "") + (" (closest hits; rays with a distance tie traced again in the reference's order)" if wide == 3 else " (closest hits, not the reference's traversal order)") if wide else ""),
                 "sharding": (("tile-split 8x8 tiles" if tile_split else "sample-split frames") + f", scene replicated, {'RCCL' if args.dist_backend == 'nccl' else args.dist_backend} sum-reduce of the fp32 accumulation buffer") if distributed else "single GPU",
                 "rays_per_camera_sample": round(total_rays / max(total_samples, 1), 4),
             },
@@ -219,8 +219,9 @@ def main():
             # Informational figures, outside the timed region above: the same workload on the opt-in
             # four-wide trees (RT_OPT_WIDE_BVH 1: collapsed from the uploaded trees, 2: from trees the
             # library builds itself), which find the same closest hits but may pick the other triangle
-            # of an exact distance tie.  `value` stays the reference-order figure.
-            for mode, key in ((1, "optin_wide_tree"), (2, "optin_wide_tree_rebuilt")):
+            # of an exact distance tie, and 3: as 2 with such rays traced again in the reference's
+            # order.  `value` stays the reference-order figure.
+            for mode, key in ((1, "optin_wide_tree"), (2, "optin_wide_tree_rebuilt"), (3, "optin_wide_tree_rebuilt_exact_ties")):
                 be.set_option(capi.RT_OPT_WIDE_BVH, mode)
                 step(0)
                 be.reset_stats()
@@ -233,6 +234,8 @@ def main():
                 wst = be.stats()
                 out[key] = {"value": round(wst["rays"] / dt / 1e6, 3), "unit": "Mrays/s", "steps": 2, "ms_per_step": round(dt / 2 * 1e3, 3),
                             "trace_only_mrays_per_s": round(wst["rays"] / max(wst["trace_ms"] / 1e3, 1e-12) / 1e6, 2)}
+                if mode == 3:
+                    out[key]["rays_traced_again"] = int(wst["retraced"])
             be.set_option(capi.RT_OPT_WIDE_BVH, 0)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, scene, cam, rtype)

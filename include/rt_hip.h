@@ -66,6 +66,7 @@ typedef struct rt_stats {
     double total_ms;        /* device time of rt_render as a whole */
     uint64_t trace_launches;
     uint64_t max_stack;     /* most traversal-stack entries any ray held (only if counters enabled) */
+    uint64_t retraced;      /* RT_OPT_WIDE_BVH 3: rays traced a second time, in the reference's order, after a distance tie */
 } rt_stats;
 
 /* Creates a context on HIP device `device`.  Replaces the GL context +
@@ -191,6 +192,11 @@ int rt_set_counters(rt_ctx *ctx, int enabled);
  *                            uploaded node section is then only validated.  Same closest hits, same
  *                            tie caveat, about a third of the node visits and half of the triangle
  *                            tests of the reference order.
+ *                            3: as 2, without the tie caveat: a ray that met two triangles of one
+ *                            model at its closest distance is traced a second time by the
+ *                            reference-order kernel over the uploaded trees, whose answer replaces
+ *                            the first (rt_stats.retraced counts such rays; 4 bytes of device
+ *                            memory per ray slot hold the list).
  *   RT_OPT_HERO_WAVELENGTH   1: the Spectral integrator built with HERO_WAVELENGTH_ENABLE 1
  *                            (src/RayTracer.cpp:607, 1257-1280, 1357-1364): every camera sample traces
  *                            four wavelengths, spread over the range from one random offset, along

@@ -59,6 +59,7 @@ class RtStats(C.Structure):
         ("total_ms", C.c_double),
         ("trace_launches", C.c_uint64),
         ("max_stack", C.c_uint64),
+        ("retraced", C.c_uint64),
     ]
 
 

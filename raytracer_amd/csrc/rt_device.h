@@ -59,14 +59,15 @@ constexpr int32_t kTriAlphaTest = 1 << 30;  // triangle needs the alpha-cut text
 constexpr int32_t kTriModelMask = (1 << 30) - 1;
 
 struct ModelDesc {
-    int32_t rootRef;            // child reference of node 0 (in the four-wide tree when that mode is on)
+    int32_t rootRef;            // child reference of node 0 of the uploaded binary tree
     int32_t nodesCount, identifiersCount, lightSourcesCount;
     int32_t lightBase;          // word offset of the light identifiers (the info stream's location)
     int32_t nodeBase;           // word offset of node 0
     int32_t identBase;          // word offset of identifier 0
     int32_t vertBase;           // word offset of vertex 0
     int32_t triBase;            // index of identifier 0 in the packed triangle array
-    int32_t pad[3];
+    int32_t wideRootRef;        // child reference of the model's root in the four-wide tree (when that mode is on)
+    int32_t pad[2];
 };
 
 struct SceneView {
@@ -75,6 +76,7 @@ struct SceneView {
     const WideNode *wnodes;     // four-wide tree, null unless that mode is on
     const PackedTri *tris;
     const PackedShade *shade;   // [triangle], same index as tris
+    const PackedTri *wtris;     // four-wide trees: the triangles in THEIR leaf order; `ident` holds the index into tris
     const ModelDesc *modelDesc;
     int32_t objectCount, modelsCount, lightSourcesCount;
 };

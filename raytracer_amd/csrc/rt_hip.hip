@@ -67,7 +67,8 @@ struct rt_ctx {
     bool committed = false;
     PackedNode *dNodes = nullptr;
     WideNode *dWNodes = nullptr;    // four-wide tree (wideBvh only)
-    int wideBvh = 0;                // 0 off, 1 derived from the uploaded trees, 2 the library's own trees
+    int wideBvh = 0;                // 0 off, 1 derived from the uploaded trees, 2 the library's own trees, 3 = 2 + ties re-traced in reference order
+    PackedTri *dWTris = nullptr;    // triangles in wide-tree leaf order
     int wideStackNeed = 0;          // most stack entries a ray can hold in the four-wide tree
     PackedTri *dTris = nullptr;
     PackedShade *dShade = nullptr;
@@ -364,11 +365,11 @@ int repackScene(rt_ctx *ctx, std::vector<PackedNode> &nodes, std::vector<PackedT
 // Binary tree over one model's triangles by binned surface-area splits (16 bins per axis on the
 // triangle centres), for RT_OPT_WIDE_BVH = 2.  Nodes are emitted in pre-order through `emit(box,
 // left, right, leafRef, leaf)` with child numbers relative to the model's first node; leaves hold one
-// or two triangles (three where equal centres leave no split).  The model's packed triangle and
-// shading records are permuted into leaf order.  Boxes are the exact bounds of the vertices; the
+// or two triangles (three where equal centres leave no split).  `wtris` receives the model's packed
+// triangles in leaf order.  Boxes are the exact bounds of the vertices; the
 // margin the device arithmetic needs is added when they are quantised.
 template <typename Emit>
-bool sahTree(const std::vector<float> &mdl, const ModelDesc &d, std::vector<PackedTri> &tris, std::vector<PackedShade> &shade, Emit emit) {
+bool sahTree(const std::vector<float> &mdl, const ModelDesc &d, const std::vector<PackedTri> &tris, std::vector<PackedTri> &wtris, Emit emit) {
     const int T = d.identifiersCount;
     struct Prim { float box[6]; float centre[3]; };
     std::vector<Prim> prims((size_t)T);
@@ -485,15 +486,13 @@ bool sahTree(const std::vector<float> &mdl, const ModelDesc &d, std::vector<Pack
             todo.push_back({it.lo, mid, self, false, it.depth + 1});
         }
     }
-    // Records into leaf order, then the nodes.
-    std::vector<PackedTri> newTris((size_t)T);
-    std::vector<PackedShade> newShade((size_t)T);
+    // The triangle records in this tree's leaf order, each naming its place in `tris`; then the nodes.
     for (int i = 0; i < T; ++i) {
-        newTris[(size_t)i] = tris[(size_t)d.triBase + (size_t)order[(size_t)i]];
-        newShade[(size_t)i] = shade[(size_t)d.triBase + (size_t)order[(size_t)i]];
+        const int32_t at = d.triBase + order[(size_t)i];
+        PackedTri pt = tris[(size_t)at];
+        pt.ident = at;
+        wtris[(size_t)d.triBase + (size_t)i] = pt;
     }
-    std::copy(newTris.begin(), newTris.end(), tris.begin() + d.triBase);
-    std::copy(newShade.begin(), newShade.end(), shade.begin() + d.triBase);
     for (const Node &n : nodes) {
         const bool leaf = n.left < 0;
         const int32_t leafRef = leaf ? ~(int32_t)((((uint32_t)(d.triBase + n.lo)) << 2) | (uint32_t)(n.hi - n.lo)) : 0;
@@ -504,11 +503,15 @@ bool sahTree(const std::vector<float> &mdl, const ModelDesc &d, std::vector<Pack
 
 // Four-wide tree of every model, collapsed from the binary tree of the model stream: a node adopts
 // the children of its child with the largest box until it has four (or only leaves are left).
-// `descs` must have passed repackScene; rootRef is redirected to the new tree.
-int buildWideNodes(rt_ctx *ctx, std::vector<ModelDesc> &descs, std::vector<WideNode> &wnodes, std::vector<PackedTri> &tris, std::vector<PackedShade> &shade) {
+// `descs` must have passed repackScene; wideRootRef receives the new tree's root.
+int buildWideNodes(rt_ctx *ctx, std::vector<ModelDesc> &descs, std::vector<WideNode> &wnodes, const std::vector<PackedTri> &tris, std::vector<PackedTri> &wtris) {
     const std::vector<float> &mdl = ctx->host[RT_SLOT_MODELS];
     ctx->wideStackNeed = 0;
-    const bool rebuild = ctx->wideBvh == 2;
+    const bool rebuild = ctx->wideBvh >= 2;
+    // Triangles in the order of the trees walked, each naming its index in `tris` (what hit records
+    // and shading use): the uploaded order unless a model's tree is rebuilt below.
+    wtris = tris;
+    for (size_t i = 0; i < wtris.size(); ++i) wtris[i].ident = (int32_t)i;
 
     // All binary nodes in one array: box, children (indices into it), or the leaf reference.
     struct Bin { float box[6]; int32_t left, right; int32_t leafRef; bool leaf; };
@@ -516,12 +519,13 @@ int buildWideNodes(rt_ctx *ctx, std::vector<ModelDesc> &descs, std::vector<WideN
     std::vector<std::pair<int32_t, ModelDesc *>> roots;
     double reach = 0.0;
     for (ModelDesc &d : descs) {
+        d.wideRootRef = d.rootRef;   // a tree that is one leaf: same reference, wtris being a copy of tris there
         if (d.nodesCount <= 0) continue;
         if (rebuild && d.identifiersCount > 0) {
             // The library's own tree over the model's triangles: binned surface-area splits, leaves
-            // of one or two triangles, the packed triangle records reordered into leaf order.
+            // of one or two triangles, a copy of the triangle records in its leaf order.
             const int32_t base = (int32_t)bin.size();
-            if (!sahTree(mdl, d, tris, shade, [&](const float *box, int32_t left, int32_t right, int32_t leafRef, bool leaf) {
+            if (!sahTree(mdl, d, tris, wtris, [&](const float *box, int32_t left, int32_t right, int32_t leafRef, bool leaf) {
                     Bin b{};
                     for (int k = 0; k < 6; ++k) b.box[k] = box[k];
                     b.left = leaf ? -1 : base + left;
@@ -531,7 +535,7 @@ int buildWideNodes(rt_ctx *ctx, std::vector<ModelDesc> &descs, std::vector<WideN
                     bin.push_back(b);
                 })) return RT_ERR_SCENE;
             if (bin[(size_t)base].leaf) {
-                d.rootRef = bin[(size_t)base].leafRef;
+                d.wideRootRef = bin[(size_t)base].leafRef;
                 continue;
             }
             roots.push_back({base, &d});
@@ -575,9 +579,9 @@ int buildWideNodes(rt_ctx *ctx, std::vector<ModelDesc> &descs, std::vector<WideN
     struct Item { int32_t node; int32_t wide; int held; };   // binary node to expand, its slot, entries its ancestors keep stacked
     std::vector<Item> todo;
     for (auto &rootOf : roots) {
-        rootOf.second->rootRef = (int32_t)wnodes.size();
+        rootOf.second->wideRootRef = (int32_t)wnodes.size();
         wnodes.emplace_back();
-        todo.push_back({rootOf.first, rootOf.second->rootRef, 0});
+        todo.push_back({rootOf.first, rootOf.second->wideRootRef, 0});
     }
     while (!todo.empty()) {
         const Item it = todo.back();
@@ -681,6 +685,10 @@ int allocPathBuffers(rt_ctx *ctx, uint64_t want64) {
     if ((rc = devAlloc(ctx, &ctx->pb.neeA, want)) != RT_OK) return rc;
     if ((rc = devAlloc(ctx, &ctx->pb.neeB, want)) != RT_OK) return rc;
     if ((rc = devAlloc(ctx, &ctx->pb.neeC, want)) != RT_OK) return rc;
+    // Re-trace list of the four-wide walk: room for every ray one launch can trace.
+    ctx->pb.retraceCap = 0;
+    if ((rc = devAlloc(ctx, &ctx->pb.retrace, (size_t)want * 2)) != RT_OK) return rc;
+    ctx->pb.retraceCap = want * 2;
     // A sub-queue receives what the blocks mapped to it produce: at most its share
     // of the paths plus one block-round of slack per block feeding it.
     const size_t maxGrid = (size_t)ctx->numCUs * 16 + kSubQueues;
@@ -691,7 +699,7 @@ int allocPathBuffers(rt_ctx *ctx, uint64_t want64) {
     if ((rc = devAlloc(ctx, &ctx->pb.qExt[1], subCap * kSubQueues)) != RT_OK) return rc;
     if ((rc = devAlloc(ctx, &ctx->pb.qShadow, subCap * kSubQueues)) != RT_OK) return rc;
     if (ctx->pb.stages == nullptr) {
-        if ((rc = devAlloc(ctx, &ctx->pb.stages, (size_t)kMaxBounces + 2)) != RT_OK) return rc;
+        if ((rc = devAlloc(ctx, &ctx->pb.stages, (size_t)kMaxBounces + 3)) != RT_OK) return rc;
     }
     if (ctx->pb.counters == nullptr) {
         if ((rc = devAlloc(ctx, &ctx->pb.counters, 8)) != RT_OK) return rc;
@@ -727,7 +735,7 @@ void launchTrace(rt_ctx *ctx, int extParity, int stage) {
     // Camera rays (stage 0) stay in 64-ray packets; later stages refill idle lanes.
     // The library-built wide trees make rays short; they run best with a slightly later refill
     // (40 idle lanes: +1.5 %) unless the caller chose a value.
-    const int refill = stage == 0 ? 64 : (!ctx->refillChosen && ctx->wideBvh == 2) ? 40 : ctx->refillLanes;
+    const int refill = stage == 0 ? 64 : (!ctx->refillChosen && ctx->wideBvh >= 2) ? 40 : ctx->refillLanes;
     // Kernel variant: visit counting, LDS stack depth (24 entries let 6 blocks share a
     // CU's LDS instead of 5), alpha-cut support only when some triangle needs it.
     using TraceFn = void (*)(SceneView, PathBuffers, int, int, int, int);
@@ -753,7 +761,19 @@ void launchTrace(rt_ctx *ctx, int extParity, int stage) {
         wavesPerSimd = depthClass == 0 ? (ctx->hasAlphaTest ? RT_WALPHA : prims ? 7 : RT_W20) : depthClass == 1 ? (ctx->hasAlphaTest ? std::min(RT_WALPHA, 6) : 6) : 5;
     }
     const int grid = ctx->numCUs * wavesPerSimd;
-    hipLaunchKernelGGL(fn, dim3(grid), dim3(kBlock), 0, ctx->stream, ctx->view, ctx->pb, extParity, stage, refill, ctx->innerShare);
+    const bool exactTies = ctx->wideBvh == 3;
+    PathBuffers pb = ctx->pb;
+    if (!exactTies) pb.retrace = nullptr;
+    if (exactTies) (void)hipMemsetAsync(&ctx->pb.stages[kRetraceStage], 0, sizeof(Stage), ctx->stream);
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(kBlock), 0, ctx->stream, ctx->view, pb, extParity, stage, refill, ctx->innerShare);
+    if (exactTies) {
+        // Rays that met a same-model tie go through the reference-order kernel once more (usually none:
+        // a small grid, every wave of which finds the list empty and leaves).
+        const bool rootsInLds = ctx->modelsCount > 2 && depthClass < 2 && !ctx->countersOn;
+        const TraceFn exact = rootsInLds ? rootVariants[depthClass][ctx->hasAlphaTest ? 1 : 0][prims ? 1 : 0]
+                                         : variants[ctx->countersOn ? 1 : 0][depthClass][ctx->hasAlphaTest ? 1 : 0][prims ? 1 : 0];
+        hipLaunchKernelGGL(exact, dim3(ctx->numCUs), dim3(kBlock), 0, ctx->stream, ctx->view, pb, 2, kRetraceStage, 32, ctx->innerShare);
+    }
     if (e1) hipEventRecord(e1, ctx->stream);
     if (e0 && e1) ctx->traceEvents.push_back({e0, e1});
     ctx->traceLaunches++;
@@ -929,7 +949,7 @@ int rt_create(rt_ctx **out, int device) {
         if (v > 0) ctx->maxPaths = (uint32_t)std::min<long>(v, 1l << 30);
     }
     if (const char *env = std::getenv("RT_TILE_MAJOR")) ctx->planesInner = std::atoi(env) != 0;
-    if (const char *env = std::getenv("RT_WIDE_BVH")) ctx->wideBvh = std::min(std::max(std::atoi(env), 0), 2);
+    if (const char *env = std::getenv("RT_WIDE_BVH")) ctx->wideBvh = std::min(std::max(std::atoi(env), 0), 3);
     if (const char *env = std::getenv("RT_INNER_SHARE")) {
         int v = std::atoi(env);
         if (v >= 1 && v <= 64) ctx->innerShare = v;
@@ -947,7 +967,7 @@ void rt_destroy(rt_ctx *ctx) {
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
     for (float *p : ctx->dStream) if (p) hipFree(p);
-    void *owned[] = {ctx->dNodes, ctx->dWNodes, ctx->pb.overflow, ctx->dTris, ctx->dShade, ctx->dModelDesc, ctx->accumExternal ? nullptr : (void *)ctx->dAccum, ctx->dPartial,
+    void *owned[] = {ctx->dNodes, ctx->dWNodes, ctx->pb.overflow, ctx->pb.retrace, ctx->dWTris, ctx->dTris, ctx->dShade, ctx->dModelDesc, ctx->accumExternal ? nullptr : (void *)ctx->dAccum, ctx->dPartial,
                      ctx->pb.rays, ctx->pb.hits, ctx->pb.stA, ctx->pb.stB, ctx->pb.neeA, ctx->pb.neeB, ctx->pb.neeC,
                      ctx->pb.qExt[0], ctx->pb.qExt[1], ctx->pb.qShadow, ctx->pb.stages, ctx->pb.counters};
     for (void *p : owned) if (p) hipFree(p);
@@ -997,7 +1017,10 @@ int rt_commit_scene(rt_ctx *ctx, int objectCount, int modelsCount, int lightSour
     }
     std::vector<WideNode> wnodes;
     if (ctx->wideBvh) {
-        if ((rc = buildWideNodes(ctx, descs, wnodes, tris, shade)) != RT_OK) return rc;
+        std::vector<PackedTri> wtris;
+        if ((rc = buildWideNodes(ctx, descs, wnodes, tris, wtris)) != RT_OK) return rc;
+        if ((rc = devAlloc(ctx, &ctx->dWTris, wtris.size())) != RT_OK) return rc;
+        if (!wtris.empty()) RT_HIP(hipMemcpy(ctx->dWTris, wtris.data(), wtris.size() * sizeof(PackedTri), hipMemcpyHostToDevice));
         if ((rc = devAlloc(ctx, &ctx->dWNodes, wnodes.size())) != RT_OK) return rc;
         if (!wnodes.empty()) RT_HIP(hipMemcpy(ctx->dWNodes, wnodes.data(), wnodes.size() * sizeof(WideNode), hipMemcpyHostToDevice));
         // Stack entries that do not fit in LDS: one column per lane of every wave the grid can hold.
@@ -1026,6 +1049,7 @@ int rt_commit_scene(rt_ctx *ctx, int objectCount, int modelsCount, int lightSour
     v.textures = ctx->dStream[RT_SLOT_TEXTURES];
     v.nodes = ctx->dNodes;
     v.wnodes = ctx->wideBvh ? ctx->dWNodes : nullptr;
+    v.wtris = ctx->wideBvh ? ctx->dWTris : nullptr;
     v.tris = ctx->dTris;
     v.shade = ctx->dShade;
     v.modelDesc = ctx->dModelDesc;
@@ -1304,6 +1328,7 @@ int rt_get_stats(rt_ctx *ctx, rt_stats *out) {
     out->total_ms = ctx->totalMs;
     out->trace_launches = ctx->traceLaunches;
     out->max_stack = c[4];
+    out->retraced = c[5];
     return RT_OK;
 }
 
@@ -1368,7 +1393,7 @@ int rt_set_option(rt_ctx *ctx, int option, int value) {
             ctx->maxPaths = (uint32_t)value;
             return RT_OK;
         case RT_OPT_WIDE_BVH:
-            if (value < 0 || value > 2) return RT_ERR_INVALID;
+            if (value < 0 || value > 3) return RT_ERR_INVALID;
             if (ctx->wideBvh == value) return RT_OK;
             ctx->wideBvh = value;
             if (!ctx->committed) return RT_OK;

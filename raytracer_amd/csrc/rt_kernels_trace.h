@@ -90,12 +90,18 @@ struct LaneRay {
     float pendT, pendU, pendV;
     uint32_t pendTri, resume;
 };
+// Four-wide variants mark a ray that met two triangles of one model at the same closest distance in
+// the sign of tStop (a distance, never negative): one register fewer than a flag of its own, and
+// reading the magnitude back costs nothing.
+__device__ __forceinline__ void markTie(LaneRay &r) { r.tStop = __int_as_float(__float_as_int(r.tStop) | (int)0x80000000); }
+__device__ __forceinline__ bool hasTie(const LaneRay &r) { return __float_as_int(r.tStop) < 0; }
 
 // Root references of the first models, copied to LDS by the traversal kernel: entering a model
 // then costs an LDS read instead of a round trip to memory on every ray's critical path.
 constexpr int kRootCache = 64;
 constexpr int32_t kNoRoot = (int32_t)0x80000000;   // model without nodes; not a valid child reference
 
+template <bool WIDE>
 __device__ __forceinline__ bool enterModel(const SceneView &sc, const int32_t *rootLds, LaneRay &r, int m) {
     for (; m < sc.modelsCount; ++m) {
         int32_t root;
@@ -103,7 +109,7 @@ __device__ __forceinline__ bool enterModel(const SceneView &sc, const int32_t *r
             root = rootLds[m];
         } else {
             const ModelDesc &md = sc.modelDesc[m];
-            root = md.nodesCount > 0 ? md.rootRef : kNoRoot;
+            root = md.nodesCount > 0 ? (WIDE ? md.wideRootRef : md.rootRef) : kNoRoot;
         }
         if (root == kNoRoot) continue;
         r.model = m;
@@ -229,14 +235,18 @@ __global__ __launch_bounds__(kBlock, WIDE ? (ALPHA ? RT_WWIDE_ALPHA : RT_WWIDE)
         int32_t root = kNoRoot;
         if ((int)threadIdx.x < sc.modelsCount) {
             const ModelDesc &md = sc.modelDesc[threadIdx.x];
-            if (md.nodesCount > 0) root = md.rootRef;
+            if (md.nodesCount > 0) root = WIDE ? md.wideRootRef : md.rootRef;
         }
         rootTable[threadIdx.x] = root;
     }
     if (ROOTS) __syncthreads();
 
     Stage *st = &pb.stages[stage];
-    const uint32_t *qExt = extParity >= 0 ? pb.qExt[extParity] : nullptr;
+    // extParity 0/1: the bounce's extension queue; -1: shadow rays only; 2: the re-trace list of the
+    // four-wide walk (one sub-queue, whose count may exceed what was stored).
+    const bool retraceList = extParity == 2;
+    const uint32_t *qExt = retraceList ? pb.retrace : extParity >= 0 ? pb.qExt[extParity] : nullptr;
+    auto lengthOf = [&](const SubQueue *q) -> uint32_t { return retraceList ? min(q->count, pb.retraceCap) : q->count; };
     const int firstSource = qExt ? 0 : kSubQueues;
     const int numSources = 2 * kSubQueues - firstSource;
     const uint32_t waveId = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
@@ -309,10 +319,16 @@ __global__ __launch_bounds__(kBlock, WIDE ? (ALPHA ? RT_WWIDE_ALPHA : RT_WWIDE)
         // A later model's triangle at exactly the closest distance so far replaces the hit, a
         // triangle of the same model does not (src/RayScene.cpp:535, :405-406).  The four-wide walk
         // keeps one distance for both tests: maxT is this model's hit once mBest is set.
-        if (WIDE ? (r.mBest != kMiss && t == r.maxT) : (t >= r.tModel)) return false;
+        const bool sameModelTie = WIDE && r.mBest != kMiss && t == r.maxT;
+        if (!WIDE && t >= r.tModel) return false;
         const float u = dot(ac, dao) * invDet;
         const float v = -dot(ab, dao) * invDet;
         if (u < 0.0f || v < 0.0f || u + v > 1.0f) return false;
+        if (sameModelTie) {
+            // Which of the two the reference reports depends on its visiting order: remember it.
+            markTie(r);
+            return false;
+        }
         if (ALPHA && (__float_as_int(q1.w) & kTriAlphaTest)) {
             r.pendT = t;
             r.pendU = u;
@@ -322,7 +338,7 @@ __global__ __launch_bounds__(kBlock, WIDE ? (ALPHA ? RT_WWIDE_ALPHA : RT_WWIDE)
         }
         if (!WIDE) r.tModel = t;   // the four-wide walk keeps its closest hit in maxT alone
         r.maxT = t;
-        r.mBest = ti;
+        r.mBest = WIDE ? (uint32_t)__float_as_int(q2.w) : ti;   // wide records carry the index into tris
         r.mU = u;
         r.mV = v;
         return false;
@@ -337,7 +353,7 @@ __global__ __launch_bounds__(kBlock, WIDE ? (ALPHA ? RT_WWIDE_ALPHA : RT_WWIDE)
             // and turns the load of its length into a scalar load.
             const int src = __builtin_amdgcn_readfirstlane(source);
             SubQueue *sq = (src < kSubQueues) ? &st->ext[src] : &st->shadow[src - kSubQueues];
-            const uint32_t n = sq->count;
+            const uint32_t n = lengthOf(sq);
             const int leader = __ffsll((long long)idleMask) - 1;
             uint32_t base = n;
             if (n != 0u) {
@@ -348,7 +364,7 @@ __global__ __launch_bounds__(kBlock, WIDE ? (ALPHA ? RT_WWIDE_ALPHA : RT_WWIDE)
                 bool has = false;
                 if ((int)lane >= firstSource && (int)lane < 2 * kSubQueues) {
                     SubQueue *o = ((int)lane < kSubQueues) ? &st->ext[lane] : &st->shadow[lane - kSubQueues];
-                    has = __hip_atomic_load(&o->cursor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < o->count;
+                    has = __hip_atomic_load(&o->cursor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < lengthOf(o);
                 }
                 const unsigned long long live = __ballot(has);
                 if (live == 0ull) {
@@ -382,10 +398,11 @@ __global__ __launch_bounds__(kBlock, WIDE ? (ALPHA ? RT_WWIDE_ALPHA : RT_WWIDE)
                     } else {
                         r.inv = v3(1.0f / r.rd.x, 1.0f / r.rd.y, 1.0f / r.rd.z);
                     }
-                    r.tStop = r1.w;
+                    // (four-wide: the sign is the tie mark; no hit is nearer than a stop distance <= 0 either way)
+                    r.tStop = WIDE ? (r1.w > 0.0f ? r1.w : 0.0f) : r1.w;
                     if (PRIMS) {
                         intersectPrimitives<COUNT>(sc, r, cntTris);
-                        active = !(r.closest < r.tStop) && enterModel(sc, rootLds, r, 0);
+                        active = !(r.closest < r.tStop) && enterModel<WIDE>(sc, rootLds, r, 0);
                         if (!active) {   // no models (or already occluded): the primitive result is final
                             HitRec rec;
                             rec.t = r.closest; rec.u = r.bestU; rec.v = r.bestV; rec.id = r.bestId;
@@ -399,7 +416,7 @@ __global__ __launch_bounds__(kBlock, WIDE ? (ALPHA ? RT_WWIDE_ALPHA : RT_WWIDE)
                         HitRec rec;
                         rec.t = 1e20f; rec.u = 0.0f; rec.v = 0.0f; rec.id = kMiss;
                         *reinterpret_cast<float4 *>(&pb.hits[r.slot]) = *reinterpret_cast<const float4 *>(&rec);
-                        active = enterModel(sc, rootLds, r, 0);
+                        active = enterModel<WIDE>(sc, rootLds, r, 0);
                     }
                 }
             }
@@ -422,10 +439,12 @@ __global__ __launch_bounds__(kBlock, WIDE ? (ALPHA ? RT_WWIDE_ALPHA : RT_WWIDE)
             const int nPending = __popcll(__ballot(pending));
             if (nPending > 0 && (nPending >= 8 || nPending == nActive)) {
                 if (pending) {
-                    if (!alphaCutRejects(sc, r.pendTri, r.ro, r.rd, r.pendT)) {
+                    // pendTri counts in the leaf order being walked; the lookup and the hit record use the index into tris
+                    const uint32_t hitTri = WIDE ? (uint32_t)sc.wtris[r.pendTri].ident : r.pendTri;
+                    if (!alphaCutRejects(sc, hitTri, r.ro, r.rd, r.pendT)) {
                         if (!WIDE) r.tModel = r.pendT;
                         r.maxT = r.pendT;
-                        r.mBest = r.pendTri;
+                        r.mBest = hitTri;
                         r.mU = r.pendU;
                         r.mV = r.pendV;
                     }
@@ -475,7 +494,7 @@ __global__ __launch_bounds__(kBlock, WIDE ? (ALPHA ? RT_WWIDE_ALPHA : RT_WWIDE)
             if (WIDE && !ALPHA) {
                 // The usual leaf holds one or two triangles: fetch both in one round trip (the binary
                 // variants have no registers to spare for this: -10 % there, +2 % here).
-                const float4v *tp = reinterpret_cast<const float4v *>(&sc.tris[first]);
+                const float4v *tp = reinterpret_cast<const float4v *>(&sc.wtris[first]);
                 if (ntri > 0u) {
                     const bool two = ntri > 1u;
                     float4v a0 = tp[0], a1 = tp[1], a2 = tp[2];
@@ -494,7 +513,7 @@ __global__ __launch_bounds__(kBlock, WIDE ? (ALPHA ? RT_WWIDE_ALPHA : RT_WWIDE)
             } else {
                 for (uint32_t k = ALPHA ? r.resume : 0u; k < ntri; ++k) {
                     const uint32_t ti = first + k;
-                    const float4 *tp = reinterpret_cast<const float4 *>(&sc.tris[ti]);
+                    const float4 *tp = reinterpret_cast<const float4 *>(WIDE ? &sc.wtris[ti] : &sc.tris[ti]);
                     const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
                     pinLoaded(q0, q1, q2);   // all three in one round trip, before the determinant test
                     if (testTriangle(ti, q0, q1, q2)) {
@@ -506,7 +525,7 @@ __global__ __launch_bounds__(kBlock, WIDE ? (ALPHA ? RT_WWIDE_ALPHA : RT_WWIDE)
             if (!parked) {
                 if (ALPHA) r.resume = 0u;
                 pop = true;
-                occluded = WIDE ? (r.mBest != kMiss && r.maxT < r.tStop) : (r.tModel < r.tStop);
+                occluded = WIDE ? (r.mBest != kMiss && r.maxT < abs_(r.tStop)) : (r.tModel < r.tStop);
             }
         }
         if (pop) {
@@ -528,13 +547,19 @@ __global__ __launch_bounds__(kBlock, WIDE ? (ALPHA ? RT_WWIDE_ALPHA : RT_WWIDE)
                         *reinterpret_cast<float4 *>(&pb.hits[r.slot]) = *reinterpret_cast<const float4 *>(&rec);
                     }
                 }
-                if (occluded || !enterModel(sc, rootLds, r, r.model + 1)) {
+                if (occluded || !enterModel<WIDE>(sc, rootLds, r, r.model + 1)) {
                     if (PRIMS) {
                         uint32_t id = r.bestId;
                         if (id != kMiss && (id & kPrimBit) == 0u && !(r.afterPrimitives > r.closest)) id |= kNoTexBit;
                         HitRec rec;
                         rec.t = r.closest; rec.u = r.bestU; rec.v = r.bestV; rec.id = id;
                         *reinterpret_cast<float4 *>(&pb.hits[r.slot]) = *reinterpret_cast<const float4 *>(&rec);
+                    }
+                    if (WIDE && hasTie(r) && pb.retrace != nullptr) {
+                        // Two triangles of one model at the closest distance: the reference's winner is
+                        // the one ITS walk meets first, so this ray is traced again in that order.
+                        const uint32_t at = atomicAdd(&pb.stages[kRetraceStage].ext[0].count, 1u);
+                        if (at < pb.retraceCap) pb.retrace[at] = r.slot;
                     }
                     active = false;
                 }
@@ -543,9 +568,14 @@ __global__ __launch_bounds__(kBlock, WIDE ? (ALPHA ? RT_WWIDE_ALPHA : RT_WWIDE)
     }
 
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        unsigned long long total = 0;
-        for (int q = 0; q < kSubQueues; ++q) total += (qExt ? st->ext[q].count : 0u) + st->shadow[q].count;
-        atomicAdd(&pb.counters[0], total);
+        if (retraceList) {   // these rays were counted by the first walk; they get a count of their own
+            const uint32_t again = lengthOf(&st->ext[0]);
+            if (again != 0u) atomicAdd(&pb.counters[5], (unsigned long long)again);
+        } else {
+            unsigned long long total = 0;
+            for (int q = 0; q < kSubQueues; ++q) total += (qExt ? st->ext[q].count : 0u) + st->shadow[q].count;
+            atomicAdd(&pb.counters[0], total);
+        }
     }
     if (COUNT) {
         for (int off = 32; off > 0; off >>= 1) {

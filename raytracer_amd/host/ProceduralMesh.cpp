@@ -337,4 +337,47 @@ MeshData RandomSoup(glm::vec3 pos, float L, int nTris, int nMaterials, int nLigh
     return mesh;
 }
 
+MeshData CoplanarStack(glm::vec3 pos, float edge, int n, int copies, u32 seed) {
+    MeshData mesh;
+    n = n < 1 ? 1 : n;
+    copies = copies < 2 ? 2 : copies;
+    u32 state = seed * 2246822519u + 97u;
+    auto next = [&state]() { state = mix32(state + 0x9E3779B9u); return state; };
+    for (int c = 0; c < copies; ++c) {
+        Material mat;
+        const float h = static_cast<float>(c) / static_cast<float>(copies);
+        mat.albedo = glm::vec3(0.15f + 0.8f * h, 0.9f - 0.7f * h, (c % 3) * 0.4f + 0.1f);
+        mat.roughness = 0.3f + 0.6f * h;
+        mesh.materials.push_back(mat);
+    }
+    struct Tri { glm::vec3 p[3]; i32 material; };
+    std::vector<Tri> all;
+    const float step = edge / static_cast<float>(n);
+    for (int c = 0; c < copies; ++c)
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j) {
+                const glm::vec3 a = pos + glm::vec3(step * static_cast<float>(i), 0.0f, step * static_cast<float>(j));
+                const glm::vec3 b = a + glm::vec3(step, 0.0f, 0.0f), d = a + glm::vec3(0.0f, 0.0f, step), e = a + glm::vec3(step, 0.0f, step);
+                all.push_back({{a, d, b}, c});
+                all.push_back({{b, d, e}, c});
+            }
+    for (size_t k = all.size(); k > 1; --k) std::swap(all[k - 1], all[next() % k]);   // Fisher-Yates
+    for (const Tri &t : all) {
+        const i32 base = static_cast<i32>(mesh.vertices.size());
+        for (const glm::vec3 &p : t.p) {
+            MeshData::Vertex v;
+            v.position = p;
+            v.normal = glm::vec3(0.0f, 1.0f, 0.0f);
+            v.uv = glm::vec2(p.x, p.z);
+            mesh.vertices.push_back(v);
+        }
+        MeshData::Identifier id;
+        id.index = glm::ivec3(base, base + 1, base + 2);
+        id.materialIndex = t.material;
+        mesh.identifiers.push_back(id);
+    }
+    mesh.deriveTextureFlags();
+    return mesh;
+}
+
 }  // namespace procedural

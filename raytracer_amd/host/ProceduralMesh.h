@@ -40,4 +40,10 @@ MeshData TexturedRoom(glm::vec3 pos, float boxLen, int texSize, u32 seed);
 // The first `nLights` triangles are emissive and form the model's light set.
 MeshData RandomSoup(glm::vec3 pos, float boxLen, int nTris, int nMaterials, int nLights, u32 seed);
 
+// Distance ties on purpose: `copies` copies of the same grid of `n` x `n` squares (two triangles each)
+// in the plane y = pos.y, every copy with its own colour, shuffled so that the copies of one square
+// are far apart in the identifier list.  Whatever a ray hits, it hits `copies` triangles of one model
+// at exactly the same distance; which one a renderer reports depends on the order it visits them in.
+MeshData CoplanarStack(glm::vec3 pos, float edge, int n, int copies, u32 seed);
+
 }  // namespace procedural

@@ -193,6 +193,13 @@ bool buildNamedScene(RayScene &scene, const std::string &name, const SceneParams
         }
         return true;
     }
+    if (name == "ties") {
+        // A lit room whose floor is covered by nv coplanar copies of an nu x nu grid of squares:
+        // every hit on it is a distance tie between triangles of one model.
+        scene.addModel(procedural::CornellBox(kBoxPos, 2.0f, 0.5f, 12.0f, false, glm::vec3(0.85f)));
+        scene.addModel(procedural::CoplanarStack(kBoxPos + glm::vec3(0.2f, 0.35f, 0.2f), 1.6f, p.nu > 0 ? p.nu : 6, p.nv > 0 ? p.nv : 4, p.seed));
+        return true;
+    }
     if (name == "mixed") {
         // Non-light model first, then two light models: exercises the light-first
         // ordering of submit() and multi-model light selection.

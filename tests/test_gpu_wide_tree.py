@@ -1,4 +1,4 @@
-"""GPU: the opt-in four-wide trees (RT_OPT_WIDE_BVH 1 and 2) against the CPU checker.
+"""GPU: the opt-in four-wide trees (RT_OPT_WIDE_BVH 1, 2 and 3) against the CPU checker.
 
 The wide tree is derived from the uploaded binary tree (1) or from a tree the library builds itself
 over the same triangles (2) and finds every ray's closest hit, but not
@@ -10,6 +10,10 @@ distance the other one may win.  Bars:
   * radiance relative RMSE <= 1e-4 against the checker.
 On the scenes below there is no tie at all and everything is equal bit for bit, which is what the
 tests report on failure.
+
+Value 3 is value 2 plus an exact answer for ties: a ray that met two triangles of one model at its
+closest distance is traced once more in the reference's order.  Its bar is the default path's:
+equal to the checker bit for bit, on a scene made of nothing but ties too.
 """
 
 import numpy as np
@@ -32,9 +36,10 @@ SCENES = [
 ]
 
 
-@pytest.fixture(scope="module", params=[1, 2], ids=["from_uploaded_trees", "library_built_trees"])
+@pytest.fixture(scope="module", params=[1, 2, 3], ids=["from_uploaded_trees", "library_built_trees", "library_built_trees_exact_ties"])
 def wide(request):
-    """1: four-wide trees collapsed from the uploaded binary trees; 2: from trees the library builds itself."""
+    """1: four-wide trees collapsed from the uploaded binary trees; 2: from trees the library builds
+    itself; 3: as 2, rays with a same-model tie traced again in the reference's order."""
     b = capi.Backend(0)
     b.set_option(capi.RT_OPT_WIDE_BVH, request.param)
     b.wide_mode = request.param
@@ -133,7 +138,7 @@ def test_wide_option_rebuilds_committed_scene():
         back, _ = b.readback()
         assert b.set_option(capi.RT_OPT_WIDE_BVH, 0) is None
         with pytest.raises(capi.RtError):
-            b.set_option(capi.RT_OPT_WIDE_BVH, 3)
+            b.set_option(capi.RT_OPT_WIDE_BVH, 4)
     finally:
         b.close()
     assert rel_rmse(got, ref) <= 1e-4
@@ -162,3 +167,50 @@ def test_wide_full_size_image_against_reference_order(wide):
     assert _close(t1, t0).all()
     differing = (m0 != m1) | (i0 != i1)
     assert differing.mean() <= 1e-5, f"{int(differing.sum())} of {W * H} primary hits picked another triangle"
+
+
+TIE_SCENES = [
+    ("ties", dict(nu=6, nv=4, seed=1)),
+    ("ties", dict(nu=24, nv=7, seed=9)),
+]
+
+
+@pytest.mark.parametrize("name,kw", TIE_SCENES)
+def test_exact_ties_primary_hits(name, kw):
+    """A floor of coplanar copies: every hit on it is a tie between triangles of one model.  The
+    four-wide walk alone picks winners of its own; with the re-trace it must report the checker's."""
+    W, H = 96, 72
+    b = capi.Backend(0)
+    try:
+        b.set_option(capi.RT_OPT_WIDE_BVH, 3)
+        scene, cam = _setup(b, name, kw, W, H, 4, 1, capi.RT_TYPE_RGB)
+        gm, gi, gt, gu, gv = b.trace_primary(frame=2)
+        b.set_option(capi.RT_OPT_WIDE_BVH, 2)
+        lm, li, lt, _, _ = b.trace_primary(frame=2)
+    finally:
+        b.close()
+    om, oi, ot, ou, ov, _ = OracleScene(scene).trace_primary(cam, frame=2)
+    assert np.array_equal(gm, om) and np.array_equal(gi, oi)
+    assert np.array_equal(gt, ot) and np.array_equal(gu, ou) and np.array_equal(gv, ov)
+    # the scene does what it is for: without the re-trace some winners differ, at equal distance
+    other = (lm != om) | (li != oi)
+    assert other.any(), "no tie was resolved differently: the scene does not exercise the re-trace"
+    assert np.array_equal(lt, ot)
+
+
+@pytest.mark.parametrize("rtype", [capi.RT_TYPE_RGB, capi.RT_TYPE_SPECTRAL])
+@pytest.mark.parametrize("name,kw", TIE_SCENES)
+def test_exact_ties_radiance(name, kw, rtype):
+    W, H, frames = 64, 48, 2
+    b = capi.Backend(0)
+    try:
+        b.set_option(capi.RT_OPT_WIDE_BVH, 3)
+        scene, cam = _setup(b, name, kw, W, H, 4, 4, rtype)
+        b.reset_accum()
+        b.render(1, frames, 1)
+        got, n = b.readback()
+    finally:
+        b.close()
+    want, _ = OracleScene(scene).render(cam, rtype, 1, frames, 1)
+    assert n == frames
+    assert np.array_equal(got, want), f"{int(np.any(got != want, axis=-1).sum())} differing pixels"

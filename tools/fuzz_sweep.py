@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Differential sweep: many random scenes, HIP backend against the CPU checker, bit for bit.
 
-    python tools/fuzz_sweep.py [first_seed] [count] [wide|wide2]
+    python tools/fuzz_sweep.py [first_seed] [count] [wide|wide2|wide3]
 Prints one line per mismatch and a summary; exit status 1 if anything differed.  With a third
 argument the backend walks its opt-in four-wide trees, where a differing pixel is legitimate only
 as a distance tie between two triangles of one model; the sweep shows how often that happens.
@@ -21,8 +21,8 @@ def main():
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 100
     be = capi.Backend(0)
-    if len(sys.argv) > 3:   # "wide": four-wide trees from the uploaded ones, "wide2": the library's own
-        be.set_option(capi.RT_OPT_WIDE_BVH, 2 if sys.argv[3].endswith("2") else 1)
+    if len(sys.argv) > 3:   # "wide": four-wide trees from the uploaded ones, "wide2": the library's own, "wide3": those with exact ties
+        be.set_option(capi.RT_OPT_WIDE_BVH, int(sys.argv[3][4:] or 1))
     bad = 0
     for seed in range(first, first + count):
         rng = np.random.default_rng(seed)
