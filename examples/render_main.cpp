@@ -2,7 +2,7 @@
 // camera, engine and scene calls, with the window loop replaced by a fixed number of
 // progressive frames and the screen quad by a PNG of the display pass.
 //
-//   rt_render [--rgb] [--wide|--wide2] [--frames N] [--size WxH] [--bounces B] [--scene cornell|roughness|three]
+//   rt_render [--rgb] [--reference-order|--wide|--wide2] [--frames N] [--size WxH] [--bounces B] [--scene cornell|roughness|three]
 //             [--out file.png] [model.glb ...]
 //   scenes: cornell (mesh Cornell box + glass and metal spheres), roughness and three
 //   (RaySceneBuilder::RoughnessMetallicDemo / ThreeColorDemo)
@@ -23,13 +23,16 @@
 int main(int argc, char **argv) {
     int width = 1280, height = 720, frames = 64, bounces = 5;
     RayTracer::Type type = RayTracer::Type::Spectral;   // the reference's default integrator
-    int wide = 0;   // 1: four-wide trees from the uploaded ones, 2: from trees the library builds itself
+    // Trees the backend walks (RT_OPT_WIDE_BVH): -1 the library's default, 0 the uploaded trees in the
+    // reference's order, 1 four-wide trees from the uploaded ones, 2 from trees the library builds itself
+    int wide = -1;
     std::string sceneName = "cornell", out = "render.png";
     std::vector<std::string> models;
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
         auto next = [&]() -> const char * { return i + 1 < argc ? argv[++i] : ""; };
         if (a == "--rgb") type = RayTracer::Type::RGB;
+        else if (a == "--reference-order") wide = 0;
         else if (a == "--wide") wide = 1;
         else if (a == "--wide2") wide = 2;
         else if (a == "--frames") frames = std::atoi(next());
@@ -86,8 +89,8 @@ int main(int argc, char **argv) {
         scene.submit();   // submit scene to the GPU
     }
 
-    // Backend switch with no counterpart in the reference: the library's own four-wide trees.
-    if (wide && rt_set_option(rayEngine.getRayTracer().backend(), RT_OPT_WIDE_BVH, wide) != RT_OK) return 1;
+    // Backend switch with no counterpart in the reference: which trees the rays walk.
+    if (wide >= 0 && rt_set_option(rayEngine.getRayTracer().backend(), RT_OPT_WIDE_BVH, wide) != RT_OK) return 1;
     rayEngine.render(static_cast<u32>(frames));   // accumulate
 
     rt_ctx *ctx = rayEngine.getRayTracer().backend();

@@ -67,7 +67,9 @@ struct rt_ctx {
     bool committed = false;
     PackedNode *dNodes = nullptr;
     WideNode *dWNodes = nullptr;    // four-wide tree (wideBvh only)
-    int wideBvh = 0;                // 0 off, 1 derived from the uploaded trees, 2 the library's own trees, 3 = 2 + ties re-traced in reference order
+    int wideBvh = 3;                // asked for: 0 off, 1 derived from the uploaded trees, 2 the library's own trees, 3 = 2 + ties re-traced in reference order
+    bool wideChosen = false;        // by option or environment: then a scene the four-wide build declines is an error
+    int wideNow = 0;                // in effect for the committed scene (0 when the default was declined for it)
     PackedTri *dWTris = nullptr;    // triangles in wide-tree leaf order
     int wideStackNeed = 0;          // most stack entries a ray can hold in the four-wide tree
     PackedTri *dTris = nullptr;
@@ -735,7 +737,7 @@ void launchTrace(rt_ctx *ctx, int extParity, int stage) {
     // Camera rays (stage 0) stay in 64-ray packets; later stages refill idle lanes.
     // The library-built wide trees make rays short; they run best with a slightly later refill
     // (40 idle lanes: +1.5 %) unless the caller chose a value.
-    const int refill = stage == 0 ? 64 : (!ctx->refillChosen && ctx->wideBvh >= 2) ? 40 : ctx->refillLanes;
+    const int refill = stage == 0 ? 64 : (!ctx->refillChosen && ctx->wideNow >= 2) ? 40 : ctx->refillLanes;
     // Kernel variant: visit counting, LDS stack depth (24 entries let 6 blocks share a
     // CU's LDS instead of 5), alpha-cut support only when some triangle needs it.
     using TraceFn = void (*)(SceneView, PathBuffers, int, int, int, int);
@@ -751,7 +753,7 @@ void launchTrace(rt_ctx *ctx, int extParity, int stage) {
     const bool prims = ctx->objectCount > 0;
     TraceFn fn;
     int wavesPerSimd;
-    if (ctx->wideBvh) {
+    if (ctx->wideNow) {
         fn = wideVariants[ctx->countersOn ? 1 : 0][ctx->modelsCount > 2 ? 1 : 0][ctx->hasAlphaTest ? 1 : 0][prims ? 1 : 0];
         wavesPerSimd = ctx->hasAlphaTest ? RT_WWIDE_ALPHA : RT_WWIDE;
     } else {
@@ -761,7 +763,7 @@ void launchTrace(rt_ctx *ctx, int extParity, int stage) {
         wavesPerSimd = depthClass == 0 ? (ctx->hasAlphaTest ? RT_WALPHA : prims ? 7 : RT_W20) : depthClass == 1 ? (ctx->hasAlphaTest ? std::min(RT_WALPHA, 6) : 6) : 5;
     }
     const int grid = ctx->numCUs * wavesPerSimd;
-    const bool exactTies = ctx->wideBvh == 3;
+    const bool exactTies = ctx->wideNow == 3;
     PathBuffers pb = ctx->pb;
     if (!exactTies) pb.retrace = nullptr;
     if (exactTies) (void)hipMemsetAsync(&ctx->pb.stages[kRetraceStage], 0, sizeof(Stage), ctx->stream);
@@ -949,7 +951,10 @@ int rt_create(rt_ctx **out, int device) {
         if (v > 0) ctx->maxPaths = (uint32_t)std::min<long>(v, 1l << 30);
     }
     if (const char *env = std::getenv("RT_TILE_MAJOR")) ctx->planesInner = std::atoi(env) != 0;
-    if (const char *env = std::getenv("RT_WIDE_BVH")) ctx->wideBvh = std::min(std::max(std::atoi(env), 0), 3);
+    if (const char *env = std::getenv("RT_WIDE_BVH")) {
+        ctx->wideBvh = std::min(std::max(std::atoi(env), 0), 3);
+        ctx->wideChosen = true;
+    }
     if (const char *env = std::getenv("RT_INNER_SHARE")) {
         int v = std::atoi(env);
         if (v >= 1 && v <= 64) ctx->innerShare = v;
@@ -1016,9 +1021,17 @@ int rt_commit_scene(rt_ctx *ctx, int objectCount, int modelsCount, int lightSour
         ctx->dStreamWords[s] = ctx->host[s].size();
     }
     std::vector<WideNode> wnodes;
-    if (ctx->wideBvh) {
-        std::vector<PackedTri> wtris;
-        if ((rc = buildWideNodes(ctx, descs, wnodes, tris, wtris)) != RT_OK) return rc;
+    std::vector<PackedTri> wtris;
+    ctx->wideNow = ctx->wideBvh;
+    if (ctx->wideNow) {
+        rc = buildWideNodes(ctx, descs, wnodes, tris, wtris);
+        // A scene the four-wide build cannot take (coordinates beyond its box arithmetic, NaN) is
+        // walked in the reference's order, as it would be with the option off, unless the caller
+        // asked for the four-wide trees by name.
+        if (rc == RT_ERR_SCENE && !ctx->wideChosen) ctx->wideNow = 0;
+        else if (rc != RT_OK) return rc;
+    }
+    if (ctx->wideNow) {
         if ((rc = devAlloc(ctx, &ctx->dWTris, wtris.size())) != RT_OK) return rc;
         if (!wtris.empty()) RT_HIP(hipMemcpy(ctx->dWTris, wtris.data(), wtris.size() * sizeof(PackedTri), hipMemcpyHostToDevice));
         if ((rc = devAlloc(ctx, &ctx->dWNodes, wnodes.size())) != RT_OK) return rc;
@@ -1048,8 +1061,8 @@ int rt_commit_scene(rt_ctx *ctx, int objectCount, int modelsCount, int lightSour
     v.models = ctx->dStream[RT_SLOT_MODELS];
     v.textures = ctx->dStream[RT_SLOT_TEXTURES];
     v.nodes = ctx->dNodes;
-    v.wnodes = ctx->wideBvh ? ctx->dWNodes : nullptr;
-    v.wtris = ctx->wideBvh ? ctx->dWTris : nullptr;
+    v.wnodes = ctx->wideNow ? ctx->dWNodes : nullptr;
+    v.wtris = ctx->wideNow ? ctx->dWTris : nullptr;
     v.tris = ctx->dTris;
     v.shade = ctx->dShade;
     v.modelDesc = ctx->dModelDesc;
@@ -1394,6 +1407,7 @@ int rt_set_option(rt_ctx *ctx, int option, int value) {
             return RT_OK;
         case RT_OPT_WIDE_BVH:
             if (value < 0 || value > 3) return RT_ERR_INVALID;
+            ctx->wideChosen = true;
             if (ctx->wideBvh == value) return RT_OK;
             ctx->wideBvh = value;
             if (!ctx->committed) return RT_OK;

@@ -9,9 +9,15 @@ from oracle_binding import OracleScene
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def backend():
+@pytest.fixture(scope="module", params=[3, 0], ids=["default_trees", "reference_order_walk"])
+def backend(request):
+    """Every test runs twice: on the library's default (its own four-wide trees, rays with a distance
+    tie traced again in the reference's order) and on the plain reference-order walk of the uploaded
+    trees (RT_OPT_WIDE_BVH 0).  Both have the same bar: the checker's result."""
     b = capi.Backend(0)
+    if request.param != 3:
+        b.set_option(capi.RT_OPT_WIDE_BVH, request.param)
+    b.tree_mode = request.param
     yield b
     b.close()
 

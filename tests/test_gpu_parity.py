@@ -29,9 +29,15 @@ SCENES = [
 ]
 
 
-@pytest.fixture(scope="module")
-def backend():
+@pytest.fixture(scope="module", params=[3, 0], ids=["default_trees", "reference_order_walk"])
+def backend(request):
+    """Every test runs twice: on the library's default (its own four-wide trees, rays with a distance
+    tie traced again in the reference's order) and on the plain reference-order walk of the uploaded
+    trees (RT_OPT_WIDE_BVH 0).  Both have the same bar: the checker's result."""
     b = capi.Backend(0)
+    if request.param != 3:
+        b.set_option(capi.RT_OPT_WIDE_BVH, request.param)
+    b.tree_mode = request.param
     yield b
     b.close()
 
@@ -179,7 +185,9 @@ def test_tile_split_shards_partition_the_image(backend):
 def test_ray_counts_match_checker(backend):
     W, H = 48, 48
     scene, cam = _setup(backend, "mixed", dict(nu=64, nv=12), W, H, 4, 4, capi.RT_TYPE_RGB)
-    # Full closest-hit walks for every ray, so the visit counts are the reference algorithm's.
+    # Full closest-hit walks of the uploaded trees for every ray, so the visit counts are the
+    # reference algorithm's.
+    backend.set_option(capi.RT_OPT_WIDE_BVH, 0)
     backend.set_option(capi.RT_OPT_SHADOW_EARLY_OUT, 0)
     backend.set_frame(cam, scene.sky, capi.RT_TYPE_RGB)
     backend.set_counters(True)
@@ -188,6 +196,7 @@ def test_ray_counts_match_checker(backend):
     st = backend.stats()
     backend.set_counters(False)
     backend.set_option(capi.RT_OPT_SHADOW_EARLY_OUT, 1)
+    backend.set_option(capi.RT_OPT_WIDE_BVH, backend.tree_mode)
     _, ost = OracleScene(scene).render(cam, 0, 1, 2, 1)
     assert st["rays"] == ost["rays"]
     assert st["node_visits"] == ost["node_visits"]
@@ -389,7 +398,7 @@ def test_sah_tree_mode_matches_checker(backend, rtype):
     assert np.array_equal(got, want, equal_nan=True)
 
 
-@pytest.mark.parametrize("flags", [[], ["--wide"], ["--wide2"]])
+@pytest.mark.parametrize("flags", [[], ["--reference-order"], ["--wide"], ["--wide2"]])
 def test_cpp_example_program_renders_the_same_picture(tmp_path, flags):
     """examples/rt_render drives the C++ host API the way the reference's main() does; its PNG must
     equal the display pass of the same scene rendered through the C ABI from here (also when the

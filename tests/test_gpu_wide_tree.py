@@ -1,4 +1,4 @@
-"""GPU: the opt-in four-wide trees (RT_OPT_WIDE_BVH 1, 2 and 3) against the CPU checker.
+"""GPU: the four-wide trees (RT_OPT_WIDE_BVH 1, 2 and 3, the last being the default) against the CPU checker.
 
 The wide tree is derived from the uploaded binary tree (1) or from a tree the library builds itself
 over the same triangles (2) and finds every ray's closest hit, but not
@@ -121,6 +121,7 @@ def test_wide_option_rebuilds_committed_scene():
     W, H = 64, 48
     b = capi.Backend(0)
     try:
+        b.set_option(capi.RT_OPT_WIDE_BVH, 0)
         scene, cam = _setup(b, "cornell_knot", dict(nu=96, nv=16), W, H, 3, 4, capi.RT_TYPE_RGB)
         b.render(1, 2, 1)
         ref, _ = b.readback()
@@ -154,6 +155,7 @@ def test_wide_full_size_image_against_reference_order(wide):
     cam = capi.make_camera(width=W, height=H, bounces=4, ray_per_pixel=1)
     out = []
     b = capi.Backend(0)
+    b.set_option(capi.RT_OPT_WIDE_BVH, 0)
     try:
         for be in (b, wide):
             be.upload_scene(scene)
@@ -214,3 +216,37 @@ def test_exact_ties_radiance(name, kw, rtype):
     want, _ = OracleScene(scene).render(cam, rtype, 1, frames, 1)
     assert n == frames
     assert np.array_equal(got, want), f"{int(np.any(got != want, axis=-1).sum())} differing pixels"
+
+
+def test_scene_beyond_the_wide_box_arithmetic_falls_back_to_the_reference_walk():
+    """Coordinates beyond 1e15 do not fit the 8-bit child boxes.  Left at its default the library
+    then walks the uploaded trees in the reference's order (the checker's result, as always);
+    asked by option for four-wide trees of its own it refuses the scene."""
+    W, H = 48, 36
+    scene = capi.Scene("cornell_knot", nu=32, nv=8)
+    info = scene.streams[3].view(np.int32).reshape(-1, 4)
+    idents, lights, nodes, location = (int(x) for x in info[1])
+    vertex0 = location + lights * 5 + nodes * 9 + idents * 5
+    scene.streams[4][vertex0] = 1e18
+    cam = capi.make_camera(width=W, height=H, bounces=3, ray_per_pixel=1)
+    b = capi.Backend(0)
+    try:
+        b.upload_scene(scene)
+        b.resize(W, H)
+        b.set_frame(cam, scene.sky, capi.RT_TYPE_RGB)
+        b.render(1, 2, 1)
+        got, _ = b.readback()
+        want, _ = OracleScene(scene).render(cam, capi.RT_TYPE_RGB, 1, 2, 1)
+        assert np.array_equal(got, want, equal_nan=True)
+        for mode in (2, 3):              # (1 takes the uploaded boxes as they are)
+            with pytest.raises(capi.RtError):
+                b.set_option(capi.RT_OPT_WIDE_BVH, mode)   # re-commits a committed scene at once
+                b.upload_scene(scene)                      # (a refused commit leaves the context without one)
+        b.set_option(capi.RT_OPT_WIDE_BVH, 0)
+        b.upload_scene(scene)
+        b.reset_accum()
+        b.render(1, 2, 1)
+        again, _ = b.readback()
+        assert np.array_equal(again, want, equal_nan=True)
+    finally:
+        b.close()
