@@ -25,6 +25,12 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+TREES = {   # RT_OPT_WIDE_BVH
+    0: "uploaded trees walked in the reference's order",
+    1: "four-wide trees collapsed from the uploaded trees (closest hits; the other triangle of a distance tie may win)",
+    2: "the library's four-wide SAH trees (closest hits; the other triangle of a distance tie may win)",
+    3: "the library's four-wide SAH trees, rays that met a distance tie traced again in the reference's order (library default)",
+}
 
 
 def parse():
@@ -41,8 +47,10 @@ def parse():
     ap.add_argument("--tex-size", type=int, default=0, help="texture edge of the textured scenes (0 = scene default)")
     ap.add_argument("--bvh", choices=["reference", "sah"], default="reference",
                     help="tree builder: the reference's median split (default; the only mode whose traversal is the reference's) or the opt-in SAH build")
-    ap.add_argument("--wide", type=int, nargs="?", const=1, default=0, choices=[0, 1, 2, 3],
-                    help="opt-in four-wide trees (RT_OPT_WIDE_BVH): closest hits, not the reference's visiting order; 1 = from the uploaded trees, 2 = the library's own SAH trees, 3 = as 2 with distance ties re-traced in the reference's order")
+    ap.add_argument("--wide", type=int, nargs="?", const=1, default=None, choices=[0, 1, 2, 3],
+                    help="trees the rays walk (RT_OPT_WIDE_BVH; default: the library's, 3): 0 = the uploaded trees in the reference's visiting order, "
+                         "1 = four-wide trees from the uploaded trees, 2 = from the library's own SAH trees (1 and 2: closest hits, but the other triangle of a distance tie may win), "
+                         "3 = as 2 with rays that met a distance tie traced again in the reference's order")
     ap.add_argument("--scene", default="cornell_knot")
     ap.add_argument("--spectral", action="store_true")
     ap.add_argument("--hero", action="store_true", help="Spectral with four wavelengths per camera sample (the reference's HERO_WAVELENGTH_ENABLE 1)")
@@ -51,7 +59,7 @@ def parse():
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend; gloo + --one-device rehearses the N>1 path on a single GPU")
     ap.add_argument("--one-device", action="store_true", help="rehearsal only: every rank uses GPU 0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-optin", action="store_true", help="skip the informational opt-in four-wide-tree figure")
+    ap.add_argument("--no-optin", action="store_true", help="skip the informational figures for the other settings of RT_OPT_WIDE_BVH")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
     return ap.parse_args()
 
@@ -85,11 +93,11 @@ def main():
     cam = capi.make_camera(width=args.width, height=args.height, bounces=args.bounces, ray_per_pixel=1)
 
     be = capi.Backend(local_rank)
-    if args.wide:
+    if args.wide is not None:
         be.set_option(capi.RT_OPT_WIDE_BVH, args.wide)
     if args.hero:
         be.set_option(capi.RT_OPT_HERO_WAVELENGTH, 1)
-    wide = args.wide or int(os.environ.get("RT_WIDE_BVH", "0") or 0)
+    wide = args.wide if args.wide is not None else int(os.environ.get("RT_WIDE_BVH", "3") or 3)
     be.upload_scene(scene)
     be.resize(args.width, args.height)
     # The sum buffer is a torch tensor so RCCL can reduce it in place.
@@ -188,7 +196,7 @@ def main():
                 "workload": f"{args.scene} ({'procedural dragon-class mesh, ' if 'knot' in args.scene else ''}{triangles} triangles in {scene.models_count} models), "
                             f"{args.width}x{args.height}, {args.spp} spp per {'image' if tile_split else 'GPU'} per step, primary+{args.bounces} bounces, "
                             f"{'Spectral' if args.spectral else 'RGB'} NEE+MIS" + (", hero-wavelength mode (4 wavelengths per camera sample)" if args.hero else "") + (", opt-in SAH trees (not the reference's traversal order)" if args.bvh == "sah" else "")
-                            + (", opt-in four-wide trees" + (" built by the library (SAH)" if wide >= 2 else "") + (" (closest hits; rays with a distance tie traced again in the reference's order)" if wide == 3 else " (closest hits, not the reference's traversal order)") if wide else ""),
+                            + (", " + TREES[wide]),
                 "sharding": (("tile-split 8x8 tiles" if tile_split else "sample-split frames") + f", scene replicated, {'RCCL' if args.dist_backend == 'nccl' else args.dist_backend} sum-reduce of the fp32 accumulation buffer") if distributed else "single GPU",
                 "rays_per_camera_sample": round(total_rays / max(total_samples, 1), 4),
             },
@@ -215,13 +223,14 @@ def main():
             },
             "host_scene_build_s": round(t_build, 2),
         }
-        if world == 1 and not wide and not args.no_optin:
-            # Informational figures, outside the timed region above: the same workload on the opt-in
-            # four-wide trees (RT_OPT_WIDE_BVH 1: collapsed from the uploaded trees, 2: from trees the
-            # library builds itself), which find the same closest hits but may pick the other triangle
-            # of an exact distance tie, and 3: as 2 with such rays traced again in the reference's
-            # order.  `value` stays the reference-order figure.
-            for mode, key in ((1, "optin_wide_tree"), (2, "optin_wide_tree_rebuilt"), (3, "optin_wide_tree_rebuilt_exact_ties")):
+        if world == 1 and wide == 3 and not args.no_optin:
+            # Informational figures, outside the timed region above: the same workload on the other
+            # settings of RT_OPT_WIDE_BVH.  0: the uploaded trees walked in the reference's order;
+            # 1 and 2: four-wide trees (collapsed from the uploaded trees / from trees the library
+            # builds itself) without the second walk for rays that met a distance tie, so the other
+            # triangle of such a tie may win.  `value` is the default's (3) figure.
+            out["rays_traced_again"] = int(st["retraced"])
+            for mode, key in ((0, "reference_order_walk"), (1, "wide_tree_from_uploaded_no_tie_retrace"), (2, "wide_tree_no_tie_retrace")):
                 be.set_option(capi.RT_OPT_WIDE_BVH, mode)
                 step(0)
                 be.reset_stats()
@@ -234,9 +243,7 @@ def main():
                 wst = be.stats()
                 out[key] = {"value": round(wst["rays"] / dt / 1e6, 3), "unit": "Mrays/s", "steps": 2, "ms_per_step": round(dt / 2 * 1e3, 3),
                             "trace_only_mrays_per_s": round(wst["rays"] / max(wst["trace_ms"] / 1e3, 1e-12) / 1e6, 2)}
-                if mode == 3:
-                    out[key]["rays_traced_again"] = int(wst["retraced"])
-            be.set_option(capi.RT_OPT_WIDE_BVH, 0)
+            be.set_option(capi.RT_OPT_WIDE_BVH, 3)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, scene, cam, rtype)
         print(json.dumps(out), flush=True)
@@ -247,19 +254,20 @@ def main():
 
 
 def measured_traffic(args):
-    """HBM-side bytes per k_trace launch from the committed PMC passes (profiles/r01_hbm_traffic.json).
+    """HBM-side bytes per k_trace launch from the committed PMC passes (profiles/r01_k_hbm_traffic.json).
     Counters cannot be read from inside this process, so the figure is the one measured with rocprofv3
     on this same command; it is only reported for the default workload it was measured on."""
-    path = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-    default = (args.scene == "cornell_knot" and args.bvh == "reference" and not args.wide and not args.spectral and (args.width, args.height, args.spp, args.bounces, args.nu, args.nv) == (1920, 1080, 64, 4, 2048, 213))
+    path = os.path.join(ROOT, "profiles", "r01_k_hbm_traffic.json")
+    default = (args.scene == "cornell_knot" and args.bvh == "reference" and args.wide is None and "RT_WIDE_BVH" not in os.environ and not args.spectral and (args.width, args.height, args.spp, args.bounces, args.nu, args.nv) == (1920, 1080, 64, 4, 2048, 213))
     if not default or not os.path.exists(path):
         return None, "not measured for this workload"
     with open(path) as f:
         data = json.load(f)
     for name, k in data["kernels"].items():
-        if name.startswith("k_trace<false"):
-            return k["fetch_bytes"] + k["write_bytes"], "bytes per launch, rocprofv3 FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE, profiles/r01_hbm_traffic.json"
-    return None, "k_trace not found in profiles/r01_hbm_traffic.json"
+        # the timed step's variant: no visit counting, four-wide trees (last template argument)
+        if name.startswith("k_trace<false") and name.endswith("true>"):
+            return k["fetch_bytes"] + k["write_bytes"], "bytes per launch, rocprofv3 FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE, profiles/r01_k_hbm_traffic.json"
+    return None, "k_trace not found in profiles/r01_k_hbm_traffic.json"
 
 
 def cpu_baseline(args, scene, cam, rtype):

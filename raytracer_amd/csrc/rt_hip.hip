@@ -1022,7 +1022,7 @@ int rt_commit_scene(rt_ctx *ctx, int objectCount, int modelsCount, int lightSour
     }
     std::vector<WideNode> wnodes;
     std::vector<PackedTri> wtris;
-    ctx->wideNow = ctx->wideBvh;
+    ctx->wideNow = tris.empty() ? 0 : ctx->wideBvh;   // nothing to build over analytic primitives alone
     if (ctx->wideNow) {
         rc = buildWideNodes(ctx, descs, wnodes, tris, wtris);
         // A scene the four-wide build cannot take (coordinates beyond its box arithmetic, NaN) is
