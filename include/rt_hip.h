@@ -156,7 +156,7 @@ int rt_reset_stats(rt_ctx *ctx);
 int rt_set_counters(rt_ctx *ctx, int enabled);
 
 /* Switches.  Only RT_OPT_SPECTRAL_PDF_AS_WRITTEN, RT_OPT_HERO_WAVELENGTH, RT_OPT_NEE,
- * RT_OPT_STRATIFIED and RT_OPT_WIDE_BVH can change output values; RT_OPT_HERO_WAVELENGTH,
+ * RT_OPT_STRATIFIED and RT_OPT_WIDE_BVH (values 1 and 2) can change output values; RT_OPT_HERO_WAVELENGTH,
  * RT_OPT_NEE and RT_OPT_STRATIFIED are the reference's shader-compile-time switches.
  *   RT_OPT_SHADOW_EARLY_OUT  RGB shadow rays stop at the first hit nearer than
  *                            distToLight - 1e-4: such a hit already fails the reference's
@@ -179,24 +179,31 @@ int rt_set_counters(rt_ctx *ctx, int enabled);
  *                            427).  1: pdf = 1/area, literally as src/RayTracer.cpp:1082,1165 write it.
  *   RT_OPT_TILE_MAJOR        order of the paths inside a batch: 1 (default) keeps all sample
  *                            planes of an 8x8 pixel tile adjacent, 0 orders plane by plane
- *   RT_OPT_WIDE_BVH          1: rays walk a four-wide tree with 8-bit child boxes that the library
- *                            derives from the uploaded binary tree (same leaves, same triangles).
- *                            Every ray still gets its closest hit, but the trees are not visited
- *                            in the order of hitModel (src/RayScene.cpp:681-736), so where two
- *                            triangles are hit at the same distance (shared edges, coplanar
- *                            duplicates) the other one may win.  Default 0: the reference's order,
- *                            bit-identical hits.  Rebuilds the derived tree of a committed scene.
+ *   RT_OPT_WIDE_BVH          Which trees the rays walk.  Default 3.  Changing it rebuilds the
+ *                            derived trees of a committed scene at once.
+ *                            0: the uploaded binary trees, in the order of hitModel
+ *                            (src/RayScene.cpp:681-736).
+ *                            1: a four-wide tree with 8-bit child boxes that the library derives
+ *                            from each uploaded binary tree (same leaves, same triangles).  Every
+ *                            ray still gets its closest hit, but the trees are not visited in
+ *                            hitModel's order, so where two triangles of one model are hit at the
+ *                            same distance (shared edges, coplanar duplicates) the other one may
+ *                            win.
  *                            2: as 1, but the four-wide trees are collapsed from binary trees the
  *                            library builds itself over each model's triangles (binned
- *                            surface-area splits) instead of the uploaded median-split trees; the
- *                            uploaded node section is then only validated.  Same closest hits, same
- *                            tie caveat, about a third of the node visits and half of the triangle
- *                            tests of the reference order.
+ *                            surface-area splits) instead of the uploaded median-split trees.  Same
+ *                            closest hits, same tie caveat, about a third of the node visits and
+ *                            half of the triangle tests of the reference order.
  *                            3: as 2, without the tie caveat: a ray that met two triangles of one
  *                            model at its closest distance is traced a second time by the
  *                            reference-order kernel over the uploaded trees, whose answer replaces
  *                            the first (rt_stats.retraced counts such rays; 4 bytes of device
  *                            memory per ray slot hold the list).
+ *                            The uploaded node section is validated for every value.  Values 2
+ *                            and 3 need finite coordinates within 1e15: left at the default such a
+ *                            scene is walked as with 0; chosen by this option or by the
+ *                            environment variable RT_WIDE_BVH the commit fails with RT_ERR_SCENE.
+ *                            Scenes without triangles are not affected.
  *   RT_OPT_HERO_WAVELENGTH   1: the Spectral integrator built with HERO_WAVELENGTH_ENABLE 1
  *                            (src/RayTracer.cpp:607, 1257-1280, 1357-1364): every camera sample traces
  *                            four wavelengths, spread over the range from one random offset, along
