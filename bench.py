@@ -98,7 +98,9 @@ def main():
     if args.hero:
         be.set_option(capi.RT_OPT_HERO_WAVELENGTH, 1)
     wide = args.wide if args.wide is not None else int(os.environ.get("RT_WIDE_BVH", "3") or 3)
-    be.upload_scene(scene)
+    t_commit = time.time()
+    be.upload_scene(scene)   # copies the streams and, at commit, re-packs them and builds the library's own trees
+    t_commit = time.time() - t_commit
     be.resize(args.width, args.height)
     # The sum buffer is a torch tensor so RCCL can reduce it in place.
     accum = torch.zeros(args.height, args.width, 4, dtype=torch.float32, device=f"cuda:{local_rank}")
@@ -222,6 +224,7 @@ def main():
                 "trace_only_mrays_per_s": round(st["rays"] / max(trace_s, 1e-12) / 1e6, 2),
             },
             "host_scene_build_s": round(t_build, 2),
+            "scene_upload_commit_s": round(t_commit, 2),
         }
         if world == 1 and wide == 3 and not args.no_optin:
             # Informational figures, outside the timed region above: the same workload on the other

@@ -30,7 +30,8 @@ def main():
     ap.add_argument("--bounces", type=int, default=4)
     ap.add_argument("--spectral", action="store_true")
     ap.add_argument("--hero", action="store_true", help="Spectral with four wavelengths per camera sample (HERO_WAVELENGTH_ENABLE 1)")
-    ap.add_argument("--wide", type=int, nargs="?", const=1, default=0, choices=[0, 1, 2], help="walk the opt-in four-wide trees (RT_OPT_WIDE_BVH)")
+    ap.add_argument("--wide", type=int, nargs="?", const=1, default=None, choices=[0, 1, 2, 3],
+                    help="trees the rays walk (RT_OPT_WIDE_BVH; default: the library's, 3; 0 = the uploaded trees in the reference's order)")
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--out", default="render.png")
     ap.add_argument("--pfm")
@@ -41,7 +42,7 @@ def main():
     scene = capi.Scene(a.scene, nu=a.nu, nv=a.nv)
     cam = capi.make_camera(width=a.width, height=a.height, bounces=a.bounces, ray_per_pixel=a.ray_per_pixel)
     be = capi.Backend(a.device)
-    if a.wide:
+    if a.wide is not None:
         be.set_option(capi.RT_OPT_WIDE_BVH, a.wide)
     if a.hero:
         a.spectral = True
