@@ -12,7 +12,7 @@ HOST := raytracer_amd/host
 
 # -ffp-contract=off + correctly rounded divide/sqrt: required by rt_math.h's bit-exact contract.
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt \
-            -fno-fast-math -Wall -Wno-unused-function -Wno-unused-result -Wno-unused-value -Iinclude -I$(CSRC)
+            -fno-fast-math -pthread -Wall -Wno-unused-function -Wno-unused-result -Wno-unused-value -Iinclude -I$(CSRC)
 HOSTFLAGS := -std=c++17 -O2 -fPIC -ffp-contract=off -Wall -Wextra -Wno-unused-parameter -Iinclude -I$(HOST)
 
 HOST_SRCS := $(HOST)/AABB.cpp $(HOST)/BVHTree.cpp $(HOST)/MeshData.cpp $(HOST)/GltfLoader.cpp $(HOST)/ImageIO.cpp $(HOST)/JpegDecode.cpp $(HOST)/TraceableObject.cpp $(HOST)/RayScene.cpp \

@@ -32,11 +32,14 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "rt_hip.h"
@@ -364,8 +367,14 @@ int repackScene(rt_ctx *ctx, std::vector<PackedNode> &nodes, std::vector<PackedT
     return RT_OK;
 }
 
+// Host threads for building trees at commit: RT_BUILD_THREADS, else the machine's, at most 16.
+int buildThreads() {
+    if (const char *env = std::getenv("RT_BUILD_THREADS")) return std::min(std::max(std::atoi(env), 1), 64);
+    return (int)std::min(std::max(std::thread::hardware_concurrency(), 1u), 16u);
+}
+
 // Binary tree over one model's triangles by binned surface-area splits (16 bins per axis on the
-// triangle centres), for RT_OPT_WIDE_BVH = 2.  Nodes are emitted in pre-order through `emit(box,
+// triangle centres), for RT_OPT_WIDE_BVH 2 and 3.  Nodes are emitted (root first) through `emit(box,
 // left, right, leafRef, leaf)` with child numbers relative to the model's first node; leaves hold one
 // or two triangles (three where equal centres leave no split).  `wtris` receives the model's packed
 // triangles in leaf order.  Boxes are the exact bounds of the vertices; the
@@ -393,8 +402,6 @@ bool sahTree(const std::vector<float> &mdl, const ModelDesc &d, const std::vecto
     for (int t = 0; t < T; ++t) order[(size_t)t] = t;
 
     struct Node { float box[6]; int32_t left, right, lo, hi; };
-    std::vector<Node> nodes;
-    nodes.reserve((size_t)T);
     auto bounds = [&](int lo, int hi, float *box) {
         for (int k = 0; k < 3; ++k) { box[k] = INFINITY; box[3 + k] = -INFINITY; }
         for (int i = lo; i < hi; ++i)
@@ -407,85 +414,182 @@ bool sahTree(const std::vector<float> &mdl, const ModelDesc &d, const std::vecto
         const double ex = (double)b[3] - b[0], ey = (double)b[4] - b[1], ez = (double)b[5] - b[2];
         return ex * ey + ey * ez + ez * ex;
     };
-    // Pre-order with an explicit stack: a node is numbered when it is taken off the stack, its left
-    // subtree follows it directly, and the parent's right link is patched when that child is numbered.
-    struct Todo { int lo, hi, parent; bool isRight; int depth; };
-    std::vector<Todo> todo{{0, T, -1, false, 0}};
     constexpr int kBins = 16;
-    while (!todo.empty()) {
-        const Todo it = todo.back();
-        todo.pop_back();
-        const int32_t self = (int32_t)nodes.size();
-        nodes.emplace_back();
-        if (it.parent >= 0) (it.isRight ? nodes[(size_t)it.parent].right : nodes[(size_t)it.parent].left) = self;
-        Node n{};
-        bounds(it.lo, it.hi, n.box);
-        n.lo = it.lo;
-        n.hi = it.hi;
-        n.left = n.right = -1;
-        const int count = it.hi - it.lo;
-        int mid = -1;
-        if (count > 2) {
-            float cb[6];
+    const int workers = T >= 65536 ? buildThreads() : 1;
+    // Runs fn(part, a, b) over `parts` equal pieces of [lo, hi), piece 0 on this thread.
+    auto forked = [](int parts, int lo, int hi, auto fn) {
+        const long long count = hi - lo;
+        std::vector<std::thread> pool;
+        for (int t = 1; t < parts; ++t) pool.emplace_back(fn, t, lo + (int)(count * t / parts), lo + (int)(count * (t + 1) / parts));
+        fn(0, lo, lo + (int)(count / parts));
+        for (std::thread &th : pool) th.join();
+    };
+    struct Bins {
+        int counts[3][kBins];
+        float boxes[3][kBins][6];
+        float cb[6];
+        void clear() {
             for (int k = 0; k < 3; ++k) { cb[k] = INFINITY; cb[3 + k] = -INFINITY; }
-            for (int i = it.lo; i < it.hi; ++i)
+            for (auto &axis : counts) for (int &c : axis) c = 0;
+            for (auto &axis : boxes) for (auto &bb : axis) for (int k = 0; k < 3; ++k) { bb[k] = INFINITY; bb[3 + k] = -INFINITY; }
+        }
+    };
+    // Where to cut order[lo, hi): partitions the range and returns the first index of the right
+    // part, or -1 for a leaf.  Touches nothing outside the range.  With mayFork the scans of a long
+    // range are shared among threads; minima, maxima and counts merge exactly, so the cut is the same.
+    auto split = [&](int lo, int hi, int depth, bool mayFork) -> int {
+        const int count = hi - lo;
+        if (count <= 2) return -1;
+        const int parts = mayFork ? std::max(1, std::min(workers, count / 8192)) : 1;
+        std::vector<Bins> partial((size_t)parts);
+        for (Bins &pb : partial) pb.clear();
+        forked(parts, lo, hi, [&](int part, int a, int b) {
+            float *cb = partial[(size_t)part].cb;
+            for (int i = a; i < b; ++i)
                 for (int k = 0; k < 3; ++k) {
                     cb[k] = std::min(cb[k], prims[(size_t)order[(size_t)i]].centre[k]);
                     cb[3 + k] = std::max(cb[3 + k], prims[(size_t)order[(size_t)i]].centre[k]);
                 }
-            double bestCost = INFINITY;
-            int bestAxis = -1, bestBin = -1;
-            if (it.depth < 48) {
-                for (int axis = 0; axis < 3; ++axis) {
-                    const double extent = (double)cb[3 + axis] - cb[axis];
-                    if (!(extent > 0.0)) continue;
-                    int counts[kBins] = {0};
-                    float boxes[kBins][6];
-                    for (auto &b : boxes) for (int k = 0; k < 3; ++k) { b[k] = INFINITY; b[3 + k] = -INFINITY; }
-                    for (int i = it.lo; i < it.hi; ++i) {
-                        const Prim &p = prims[(size_t)order[(size_t)i]];
-                        int b = (int)(kBins * (((double)p.centre[axis] - cb[axis]) / extent));
-                        b = std::min(std::max(b, 0), kBins - 1);
-                        counts[b]++;
-                        for (int k = 0; k < 3; ++k) { boxes[b][k] = std::min(boxes[b][k], p.box[k]); boxes[b][3 + k] = std::max(boxes[b][3 + k], p.box[3 + k]); }
-                    }
-                    double rightArea[kBins];
-                    int rightCount[kBins];
-                    float acc[6];
-                    for (int k = 0; k < 3; ++k) { acc[k] = INFINITY; acc[3 + k] = -INFINITY; }
-                    int c = 0;
-                    for (int b = kBins - 1; b > 0; --b) {
-                        for (int k = 0; k < 3; ++k) { acc[k] = std::min(acc[k], boxes[b][k]); acc[3 + k] = std::max(acc[3 + k], boxes[b][3 + k]); }
-                        c += counts[b];
-                        rightArea[b] = c ? halfArea(acc) : 0.0;
-                        rightCount[b] = c;
-                    }
-                    for (int k = 0; k < 3; ++k) { acc[k] = INFINITY; acc[3 + k] = -INFINITY; }
-                    c = 0;
-                    for (int b = 0; b < kBins - 1; ++b) {
-                        for (int k = 0; k < 3; ++k) { acc[k] = std::min(acc[k], boxes[b][k]); acc[3 + k] = std::max(acc[3 + k], boxes[b][3 + k]); }
-                        c += counts[b];
-                        if (c == 0 || rightCount[b + 1] == 0) continue;
-                        const double cost = halfArea(acc) * c + rightArea[b + 1] * rightCount[b + 1];
-                        if (cost < bestCost) { bestCost = cost; bestAxis = axis; bestBin = b; }
+        });
+        float cb[6];
+        for (int k = 0; k < 3; ++k) { cb[k] = INFINITY; cb[3 + k] = -INFINITY; }
+        for (const Bins &pb : partial)
+            for (int k = 0; k < 3; ++k) { cb[k] = std::min(cb[k], pb.cb[k]); cb[3 + k] = std::max(cb[3 + k], pb.cb[3 + k]); }
+        double extents[3];
+        for (int axis = 0; axis < 3; ++axis) extents[axis] = (double)cb[3 + axis] - cb[axis];
+        double bestCost = INFINITY;
+        int bestAxis = -1, bestBin = -1;
+        if (depth < 48) {
+            forked(parts, lo, hi, [&](int part, int a, int b) {
+                Bins &mine = partial[(size_t)part];
+                for (int i = a; i < b; ++i) {
+                    const Prim &pr = prims[(size_t)order[(size_t)i]];
+                    for (int axis = 0; axis < 3; ++axis) {
+                        if (!(extents[axis] > 0.0)) continue;
+                        int bin = (int)(kBins * (((double)pr.centre[axis] - cb[axis]) / extents[axis]));
+                        bin = std::min(std::max(bin, 0), kBins - 1);
+                        mine.counts[axis][bin]++;
+                        float *bb = mine.boxes[axis][bin];
+                        for (int k = 0; k < 3; ++k) { bb[k] = std::min(bb[k], pr.box[k]); bb[3 + k] = std::max(bb[3 + k], pr.box[3 + k]); }
                     }
                 }
+            });
+            Bins &all = partial[0];
+            for (size_t t = 1; t < partial.size(); ++t)
+                for (int axis = 0; axis < 3; ++axis)
+                    for (int bin = 0; bin < kBins; ++bin) {
+                        all.counts[axis][bin] += partial[t].counts[axis][bin];
+                        for (int k = 0; k < 3; ++k) {
+                            all.boxes[axis][bin][k] = std::min(all.boxes[axis][bin][k], partial[t].boxes[axis][bin][k]);
+                            all.boxes[axis][bin][3 + k] = std::max(all.boxes[axis][bin][3 + k], partial[t].boxes[axis][bin][3 + k]);
+                        }
+                    }
+            for (int axis = 0; axis < 3; ++axis) {
+                if (!(extents[axis] > 0.0)) continue;
+                const int *counts = all.counts[axis];
+                float (*boxes)[6] = all.boxes[axis];
+                double rightArea[kBins];
+                int rightCount[kBins];
+                float acc[6];
+                for (int k = 0; k < 3; ++k) { acc[k] = INFINITY; acc[3 + k] = -INFINITY; }
+                int c = 0;
+                for (int bin = kBins - 1; bin > 0; --bin) {
+                    for (int k = 0; k < 3; ++k) { acc[k] = std::min(acc[k], boxes[bin][k]); acc[3 + k] = std::max(acc[3 + k], boxes[bin][3 + k]); }
+                    c += counts[bin];
+                    rightArea[bin] = c ? halfArea(acc) : 0.0;
+                    rightCount[bin] = c;
+                }
+                for (int k = 0; k < 3; ++k) { acc[k] = INFINITY; acc[3 + k] = -INFINITY; }
+                c = 0;
+                for (int bin = 0; bin < kBins - 1; ++bin) {
+                    for (int k = 0; k < 3; ++k) { acc[k] = std::min(acc[k], boxes[bin][k]); acc[3 + k] = std::max(acc[3 + k], boxes[bin][3 + k]); }
+                    c += counts[bin];
+                    if (c == 0 || rightCount[bin + 1] == 0) continue;
+                    const double cost = halfArea(acc) * c + rightArea[bin + 1] * rightCount[bin + 1];
+                    if (cost < bestCost) { bestCost = cost; bestAxis = axis; bestBin = bin; }
+                }
             }
-            if (bestAxis >= 0) {
-                const double extent = (double)cb[3 + bestAxis] - cb[bestAxis];
-                auto first = order.begin() + it.lo, last = order.begin() + it.hi;
-                auto split = std::partition(first, last, [&](int32_t t) {
-                    int b = (int)(kBins * (((double)prims[(size_t)t].centre[bestAxis] - cb[bestAxis]) / extent));
-                    return std::min(std::max(b, 0), kBins - 1) <= bestBin;
-                });
-                mid = (int)(split - order.begin());
-            }
-            if (mid <= it.lo || mid >= it.hi) mid = count > 3 ? it.lo + count / 2 : -1;   // equal centres: halve, or keep three together
         }
-        nodes[(size_t)self] = n;
-        if (mid > 0) {
-            todo.push_back({mid, it.hi, self, true, it.depth + 1});
-            todo.push_back({it.lo, mid, self, false, it.depth + 1});
+        int mid = -1;
+        if (bestAxis >= 0) {
+            const double extent = (double)cb[3 + bestAxis] - cb[bestAxis];
+            auto first = order.begin() + lo, last = order.begin() + hi;
+            auto cut = std::partition(first, last, [&](int32_t t) {
+                int bin = (int)(kBins * (((double)prims[(size_t)t].centre[bestAxis] - cb[bestAxis]) / extent));
+                return std::min(std::max(bin, 0), kBins - 1) <= bestBin;
+            });
+            mid = (int)(cut - order.begin());
+        }
+        if (mid <= lo || mid >= hi) mid = count > 3 ? lo + count / 2 : -1;   // equal centres: halve, or keep three together
+        return mid;
+    };
+    // Builds the subtree over order[lo, hi) into `out` (child numbers index `out`): a node is
+    // numbered when it is taken off the stack, its left subtree follows it directly, and the
+    // parent's right link is patched when that child is numbered.  Ranges of at most `defer`
+    // triangles are not expanded but listed in `later` (with the node that stands for them).
+    struct Todo { int lo, hi, parent; bool isRight; int depth; };
+    struct Deferred { int lo, hi, depth; int32_t node; };
+    auto build = [&](int lo0, int hi0, int depth0, std::vector<Node> &out, int defer, std::vector<Deferred> *later) {
+        std::vector<Todo> todo{{lo0, hi0, -1, false, depth0}};
+        while (!todo.empty()) {
+            const Todo it = todo.back();
+            todo.pop_back();
+            const int32_t self = (int32_t)out.size();
+            out.emplace_back();
+            if (it.parent >= 0) (it.isRight ? out[(size_t)it.parent].right : out[(size_t)it.parent].left) = self;
+            Node n{};
+            n.lo = it.lo;
+            n.hi = it.hi;
+            n.left = n.right = -1;
+            if (later != nullptr && it.hi - it.lo <= defer && it.hi - it.lo > 2) {
+                later->push_back({it.lo, it.hi, it.depth, self});
+                out[(size_t)self] = n;
+                continue;
+            }
+            bounds(it.lo, it.hi, n.box);
+            const int mid = split(it.lo, it.hi, it.depth, later != nullptr);
+            out[(size_t)self] = n;
+            if (mid > 0) {
+                todo.push_back({mid, it.hi, self, true, it.depth + 1});
+                todo.push_back({it.lo, mid, self, false, it.depth + 1});
+            }
+        }
+    };
+    // Large models: the top of the tree is cut on this thread until the ranges are small, then the
+    // ranges (disjoint parts of `order`) are built side by side and appended in range order, so the
+    // result does not depend on the number of threads.
+    std::vector<Node> nodes;
+    nodes.reserve((size_t)T);
+    if (workers <= 1) {
+        build(0, T, 0, nodes, 0, nullptr);
+    } else {
+        std::vector<Deferred> later;
+        build(0, T, 0, nodes, std::max(T / (workers * 4), 8192), &later);
+        std::vector<std::vector<Node>> parts(later.size());
+        std::atomic<size_t> next{0};
+        auto work = [&]() {
+            for (size_t k = next.fetch_add(1); k < later.size(); k = next.fetch_add(1))
+                build(later[k].lo, later[k].hi, later[k].depth, parts[k], 0, nullptr);
+        };
+        std::vector<std::thread> pool;
+        for (int w = 1; w < workers; ++w) pool.emplace_back(work);
+        work();
+        for (std::thread &th : pool) th.join();
+        for (size_t k = 0; k < later.size(); ++k) {
+            // the part's root takes the place of the node that stood for the range; the rest is appended
+            const int32_t shift = (int32_t)nodes.size() - 1;
+            auto moved = [&](int32_t c) { return c < 0 ? c : c + shift; };
+            const std::vector<Node> &part = parts[k];
+            Node root = part[0];
+            root.left = moved(root.left);
+            root.right = moved(root.right);
+            nodes[(size_t)later[k].node] = root;
+            for (size_t i = 1; i < part.size(); ++i) {
+                Node n = part[i];
+                n.left = moved(n.left);
+                n.right = moved(n.right);
+                nodes.push_back(n);
+            }
         }
     }
     // The triangle records in this tree's leaf order, each naming its place in `tris`; then the nodes.
@@ -1008,8 +1112,18 @@ int rt_commit_scene(rt_ctx *ctx, int objectCount, int modelsCount, int lightSour
     std::vector<PackedTri> tris;
     std::vector<PackedShade> shade;
     std::vector<ModelDesc> descs;
+    // RT_COMMIT_TIMING=1 prints where a commit spends its host time.
+    const bool timing = std::getenv("RT_COMMIT_TIMING") != nullptr;
+    auto clockNow = [] { return std::chrono::steady_clock::now(); };
+    auto lap = [&](const char *what, std::chrono::steady_clock::time_point &since) {
+        const auto now = clockNow();
+        if (timing) std::fprintf(stderr, "rt_commit_scene: %-28s %7.1f ms\n", what, std::chrono::duration<double, std::milli>(now - since).count());
+        since = now;
+    };
+    auto mark = clockNow();
     int rc = repackScene(ctx, nodes, tris, shade, descs);
     if (rc != RT_OK) return rc;
+    lap("validate + re-pack", mark);
 
     // Raw streams, each padded with 8 zero words so the one-past-the-end reads the
     // reference's texel fetches can make (4th channel of the last RGB texel) stay in bounds.
@@ -1020,6 +1134,7 @@ int rt_commit_scene(rt_ctx *ctx, int objectCount, int modelsCount, int lightSour
         RT_HIP(hipMemcpy(ctx->dStream[s], padded.data(), padded.size() * sizeof(float), hipMemcpyHostToDevice));
         ctx->dStreamWords[s] = ctx->host[s].size();
     }
+    lap("stream upload", mark);
     std::vector<WideNode> wnodes;
     std::vector<PackedTri> wtris;
     ctx->wideNow = tris.empty() ? 0 : ctx->wideBvh;   // nothing to build over analytic primitives alone
@@ -1031,6 +1146,7 @@ int rt_commit_scene(rt_ctx *ctx, int objectCount, int modelsCount, int lightSour
         if (rc == RT_ERR_SCENE && !ctx->wideChosen) ctx->wideNow = 0;
         else if (rc != RT_OK) return rc;
     }
+    lap("four-wide trees", mark);
     if (ctx->wideNow) {
         if ((rc = devAlloc(ctx, &ctx->dWTris, wtris.size())) != RT_OK) return rc;
         if (!wtris.empty()) RT_HIP(hipMemcpy(ctx->dWTris, wtris.data(), wtris.size() * sizeof(PackedTri), hipMemcpyHostToDevice));
@@ -1053,6 +1169,7 @@ int rt_commit_scene(rt_ctx *ctx, int objectCount, int modelsCount, int lightSour
     if (!tris.empty()) RT_HIP(hipMemcpy(ctx->dTris, tris.data(), tris.size() * sizeof(PackedTri), hipMemcpyHostToDevice));
     if (!descs.empty()) RT_HIP(hipMemcpy(ctx->dModelDesc, descs.data(), descs.size() * sizeof(ModelDesc), hipMemcpyHostToDevice));
     ctx->hTris.swap(tris);
+    lap("packed upload", mark);
 
     SceneView &v = ctx->view;
     v.objects = ctx->dStream[RT_SLOT_OBJECTS];

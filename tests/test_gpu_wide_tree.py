@@ -250,3 +250,31 @@ def test_scene_beyond_the_wide_box_arithmetic_falls_back_to_the_reference_walk()
         assert np.array_equal(again, want, equal_nan=True)
     finally:
         b.close()
+
+
+def test_library_trees_do_not_depend_on_the_number_of_build_threads(monkeypatch):
+    """Large models are built by several host threads (RT_BUILD_THREADS, read at every commit): the
+    tree, and with it every visit count, must be the one a single thread builds."""
+    W, H = 96, 64
+    scene = capi.Scene("cornell_knot", nu=512, nv=80)     # 81,920 triangles: above the threshold for threads
+    cam = capi.make_camera(width=W, height=H, bounces=3, ray_per_pixel=1)
+    seen = []
+    for threads in ("1", "7", "16"):
+        monkeypatch.setenv("RT_BUILD_THREADS", threads)
+        b = capi.Backend(0)
+        try:
+            b.upload_scene(scene)
+            b.resize(W, H)
+            b.set_frame(cam, scene.sky, capi.RT_TYPE_RGB)
+            b.set_counters(True)
+            b.reset_stats()
+            b.render(1, 2, 1)
+            img, _ = b.readback()
+            st = b.stats()
+        finally:
+            b.close()
+        seen.append((img, st["node_visits"], st["tri_tests"], st["rays"]))
+    want, _ = OracleScene(scene).render(cam, capi.RT_TYPE_RGB, 1, 2, 1)
+    for img, nodes, tris, rays in seen:
+        assert np.array_equal(img, want)
+        assert (nodes, tris, rays) == seen[0][1:]
