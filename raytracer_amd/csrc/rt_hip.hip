@@ -367,6 +367,14 @@ int repackScene(rt_ctx *ctx, std::vector<PackedNode> &nodes, std::vector<PackedT
     return RT_OK;
 }
 
+// RT_COMMIT_TIMING=1: prints the host time since `since` under the name `what`, and restarts the clock.
+void commitLap(const char *what, std::chrono::steady_clock::time_point &since) {
+    static const bool on = std::getenv("RT_COMMIT_TIMING") != nullptr;
+    const auto now = std::chrono::steady_clock::now();
+    if (on) std::fprintf(stderr, "rt_commit_scene:   %-26s %7.1f ms\n", what, std::chrono::duration<double, std::milli>(now - since).count());
+    since = now;
+}
+
 // Host threads for building trees at commit: RT_BUILD_THREADS, else the machine's, at most 16.
 int buildThreads() {
     if (const char *env = std::getenv("RT_BUILD_THREADS")) return std::min(std::max(std::atoi(env), 1), 64);
@@ -382,6 +390,7 @@ int buildThreads() {
 template <typename Emit>
 bool sahTree(const std::vector<float> &mdl, const ModelDesc &d, const std::vector<PackedTri> &tris, std::vector<PackedTri> &wtris, Emit emit) {
     const int T = d.identifiersCount;
+    auto mark = std::chrono::steady_clock::now();
     struct Prim { float box[6]; float centre[3]; };
     std::vector<Prim> prims((size_t)T);
     for (int t = 0; t < T; ++t) {
@@ -400,6 +409,7 @@ bool sahTree(const std::vector<float> &mdl, const ModelDesc &d, const std::vecto
     }
     std::vector<int32_t> order((size_t)T);
     for (int t = 0; t < T; ++t) order[(size_t)t] = t;
+    if (T >= 65536) commitLap("triangle bounds", mark);
 
     struct Node { float box[6]; int32_t left, right, lo, hi; };
     auto bounds = [&](int lo, int hi, float *box) {
@@ -592,6 +602,7 @@ bool sahTree(const std::vector<float> &mdl, const ModelDesc &d, const std::vecto
             }
         }
     }
+    if (T >= 65536) commitLap("binary tree", mark);
     // The triangle records in this tree's leaf order, each naming its place in `tris`; then the nodes.
     for (int i = 0; i < T; ++i) {
         const int32_t at = d.triBase + order[(size_t)i];
@@ -604,6 +615,7 @@ bool sahTree(const std::vector<float> &mdl, const ModelDesc &d, const std::vecto
         const int32_t leafRef = leaf ? ~(int32_t)((((uint32_t)(d.triBase + n.lo)) << 2) | (uint32_t)(n.hi - n.lo)) : 0;
         emit(n.box, n.left, n.right, leafRef, leaf);
     }
+    if (T >= 65536) commitLap("leaf-order copy + emit", mark);
     return true;
 }
 
@@ -616,8 +628,10 @@ int buildWideNodes(rt_ctx *ctx, std::vector<ModelDesc> &descs, std::vector<WideN
     const bool rebuild = ctx->wideBvh >= 2;
     // Triangles in the order of the trees walked, each naming its index in `tris` (what hit records
     // and shading use): the uploaded order unless a model's tree is rebuilt below.
+    auto mark = std::chrono::steady_clock::now();
     wtris = tris;
     for (size_t i = 0; i < wtris.size(); ++i) wtris[i].ident = (int32_t)i;
+    commitLap("triangle copy", mark);
 
     // All binary nodes in one array: box, children (indices into it), or the leaf reference.
     struct Bin { float box[6]; int32_t left, right; int32_t leafRef; bool leaf; };
@@ -669,6 +683,7 @@ int buildWideNodes(rt_ctx *ctx, std::vector<ModelDesc> &descs, std::vector<WideN
         roots.push_back({base, &d});
         for (int k = 0; k < 6; ++k) reach = std::max(reach, (double)std::fabs(bin[(size_t)base].box[k]));
     }
+    commitLap("binary trees, all models", mark);
     if (roots.empty()) return RT_OK;
     if (!(reach <= 1e15)) return RT_ERR_SCENE;   // also catches NaN
     // Margin around every box for the rounding of the plane arithmetic on the device, whose operands
@@ -774,6 +789,7 @@ int buildWideNodes(rt_ctx *ctx, std::vector<ModelDesc> &descs, std::vector<WideN
         wn.c0 = refs[0]; wn.c1 = refs[1]; wn.c2 = refs[2]; wn.c3 = refs[3];
         wnodes[(size_t)it.wide] = wn;
     }
+    commitLap("collapse to four-wide", mark);
     return RT_OK;
 }
 
