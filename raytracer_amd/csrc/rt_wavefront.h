@@ -23,7 +23,7 @@ namespace {
 #define RT_WWIDE 7     // waves/SIMD of the four-wide variants (72 VGPRs with 40 B of spills: +4 % over 6 waves without)
 #endif
 #ifndef RT_WWIDE_ALPHA
-#define RT_WWIDE_ALPHA 5
+#define RT_WWIDE_ALPHA 6   // alpha-cut four-wide variants: 80 VGPRs with 12-28 B of spills, +5 % over 5 waves without
 #endif
 constexpr int kStackDepth = 32;      // int stack[32], src/RayScene.cpp:682
 #ifndef RT_WSTACK
