@@ -838,7 +838,7 @@ int ensurePathBuffers(rt_ctx *ctx, uint64_t wantedPaths) {
     size_t freeBytes = 0, totalBytes = 0;
     if (hipMemGetInfo(&freeBytes, &totalBytes) == hipSuccess) {
         // Path state may take up to half of what is free now (plus what it already holds).
-        const uint64_t perPath = 2 * sizeof(RayRec) + 2 * sizeof(HitRec) + 5 * sizeof(float4) + 3 * sizeof(uint32_t) + 4;
+        const uint64_t perPath = 2 * sizeof(RayRec) + 2 * sizeof(HitRec) + 5 * sizeof(float4) + 3 * sizeof(uint32_t) + 4 + 2 * sizeof(uint32_t);   // the last: re-trace list
         ceiling = std::min<uint64_t>(ceiling, (freeBytes / 2 + (uint64_t)ctx->P * perPath) / perPath);
     }
     uint64_t planes = std::max<uint64_t>(1, std::min<uint64_t>(ceiling / npt, (wantedPaths + npt - 1) / npt));
