@@ -267,8 +267,9 @@ def measured_traffic(args):
     with open(path) as f:
         data = json.load(f)
     for name, k in data["kernels"].items():
-        # the timed step's variant: no visit counting, four-wide trees (last template argument)
-        if name.startswith("k_trace<false") and name.endswith("true>"):
+        # the timed step's variant: no visit counting (first template argument), four-wide trees
+        # (sixth), not the second walk of tied rays (seventh)
+        if name.startswith("k_trace<false") and name.endswith("true, false>"):
             return k["fetch_bytes"] + k["write_bytes"], "bytes per launch, rocprofv3 FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE, profiles/r01_k_hbm_traffic.json"
     return None, "k_trace not found in profiles/r01_k_hbm_traffic.json"
 

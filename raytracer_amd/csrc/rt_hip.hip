@@ -866,6 +866,10 @@ void launchTrace(rt_ctx *ctx, int extParity, int stage) {
                                                  {RT_TRACE_ROW(true, 20, false), RT_TRACE_ROW(true, 24, false), RT_TRACE_ROW(true, kStackDepth, false)}};
     static const TraceFn rootVariants[2][2][2] = {RT_TRACE_ROW(false, 20, true), RT_TRACE_ROW(false, 24, true)};
 #undef RT_TRACE_ROW
+    // The second walk of tied rays: reference order over the uploaded trees, reading the re-trace list.
+#define RT_RETRACE_ROW(S) {{k_trace<false, S, false, false, false, false, true>, k_trace<false, S, false, true, false, false, true>}, {k_trace<false, S, true, false, false, false, true>, k_trace<false, S, true, true, false, false, true>}}
+    static const TraceFn retraceVariants[3][2][2] = {RT_RETRACE_ROW(20), RT_RETRACE_ROW(24), RT_RETRACE_ROW(kStackDepth)};
+#undef RT_RETRACE_ROW
 #define RT_WIDE_ROW(C, R) {{k_trace<C, kWideStack, false, false, R, true>, k_trace<C, kWideStack, false, true, R, true>}, {k_trace<C, kWideStack, true, false, R, true>, k_trace<C, kWideStack, true, true, R, true>}}
     static const TraceFn wideVariants[2][2][2][2] = {{RT_WIDE_ROW(false, false), RT_WIDE_ROW(false, true)}, {RT_WIDE_ROW(true, false), RT_WIDE_ROW(true, true)}};
 #undef RT_WIDE_ROW
@@ -891,10 +895,8 @@ void launchTrace(rt_ctx *ctx, int extParity, int stage) {
     if (exactTies) {
         // Rays that met a same-model tie go through the reference-order kernel once more (usually none:
         // a small grid, every wave of which finds the list empty and leaves).
-        const bool rootsInLds = ctx->modelsCount > 2 && depthClass < 2 && !ctx->countersOn;
-        const TraceFn exact = rootsInLds ? rootVariants[depthClass][ctx->hasAlphaTest ? 1 : 0][prims ? 1 : 0]
-                                         : variants[ctx->countersOn ? 1 : 0][depthClass][ctx->hasAlphaTest ? 1 : 0][prims ? 1 : 0];
-        hipLaunchKernelGGL(exact, dim3(ctx->numCUs), dim3(kBlock), 0, ctx->stream, ctx->view, pb, 2, kRetraceStage, 32, ctx->innerShare);
+        const TraceFn exact = retraceVariants[depthClass][ctx->hasAlphaTest ? 1 : 0][prims ? 1 : 0];
+        hipLaunchKernelGGL(exact, dim3(ctx->numCUs), dim3(kBlock), 0, ctx->stream, ctx->view, pb, 0, kRetraceStage, 32, ctx->innerShare);
     }
     if (e1) hipEventRecord(e1, ctx->stream);
     if (e0 && e1) ctx->traceEvents.push_back({e0, e1});

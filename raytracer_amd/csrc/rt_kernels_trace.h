@@ -220,7 +220,7 @@ __device__ __forceinline__ void intersectPrimitives(const SceneView &sc, LaneRay
 // the same distance the other one may win.  (One tree over all models was tried: fewer nodes per
 // ray but slower, because lanes then mix the small models' leaves with the large model's inner
 // nodes and the two phases of the loop run emptier.)
-template <bool COUNT, int STACK, bool ALPHA, bool PRIMS, bool ROOTS, bool WIDE>
+template <bool COUNT, int STACK, bool ALPHA, bool PRIMS, bool ROOTS, bool WIDE, bool RETRACE = false>
 __global__ __launch_bounds__(kBlock, WIDE ? (ALPHA ? RT_WWIDE_ALPHA : RT_WWIDE)
                                           : (STACK <= 20 ? (ALPHA ? RT_WALPHA : PRIMS ? 7 : RT_W20) : STACK <= 24 ? (ALPHA ? (RT_WALPHA < 6 ? RT_WALPHA : 6) : 6) : 5)) void k_trace(SceneView sc, PathBuffers pb, int extParity, int stage, int refillLanes, int innerShare) {
     __shared__ int32_t stackLds[kBlock / 64][STACK][64];
@@ -242,9 +242,9 @@ __global__ __launch_bounds__(kBlock, WIDE ? (ALPHA ? RT_WWIDE_ALPHA : RT_WWIDE)
     if (ROOTS) __syncthreads();
 
     Stage *st = &pb.stages[stage];
-    // extParity 0/1: the bounce's extension queue; -1: shadow rays only; 2: the re-trace list of the
-    // four-wide walk (one sub-queue, whose count may exceed what was stored).
-    const bool retraceList = extParity == 2;
+    // extParity 0/1: the bounce's extension queue; -1: shadow rays only.  RETRACE instances read the
+    // re-trace list of the four-wide walk instead (one sub-queue, whose count may exceed what was stored).
+    constexpr bool retraceList = RETRACE;   // its own instances, so that the others carry none of it
     const uint32_t *qExt = retraceList ? pb.retrace : extParity >= 0 ? pb.qExt[extParity] : nullptr;
     auto lengthOf = [&](const SubQueue *q) -> uint32_t { return retraceList ? min(q->count, pb.retraceCap) : q->count; };
     const int firstSource = qExt ? 0 : kSubQueues;
