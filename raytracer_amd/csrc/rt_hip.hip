@@ -821,7 +821,7 @@ int allocPathBuffers(rt_ctx *ctx, uint64_t want64) {
     if ((rc = devAlloc(ctx, &ctx->pb.qExt[1], subCap * kSubQueues)) != RT_OK) return rc;
     if ((rc = devAlloc(ctx, &ctx->pb.qShadow, subCap * kSubQueues)) != RT_OK) return rc;
     if (ctx->pb.stages == nullptr) {
-        if ((rc = devAlloc(ctx, &ctx->pb.stages, (size_t)kMaxBounces + 3)) != RT_OK) return rc;
+        if ((rc = devAlloc(ctx, &ctx->pb.stages, (size_t)kMaxBounces + 2)) != RT_OK) return rc;
     }
     if (ctx->pb.counters == nullptr) {
         if ((rc = devAlloc(ctx, &ctx->pb.counters, 8)) != RT_OK) return rc;
@@ -890,13 +890,12 @@ void launchTrace(rt_ctx *ctx, int extParity, int stage) {
     const bool exactTies = ctx->wideNow == 3;
     PathBuffers pb = ctx->pb;
     if (!exactTies) pb.retrace = nullptr;
-    if (exactTies) (void)hipMemsetAsync(&ctx->pb.stages[kRetraceStage], 0, sizeof(Stage), ctx->stream);
     hipLaunchKernelGGL(fn, dim3(grid), dim3(kBlock), 0, ctx->stream, ctx->view, pb, extParity, stage, refill, ctx->innerShare);
     if (exactTies) {
         // Rays that met a same-model tie go through the reference-order kernel once more (usually none:
         // a small grid, every wave of which finds the list empty and leaves).
         const TraceFn exact = retraceVariants[depthClass][ctx->hasAlphaTest ? 1 : 0][prims ? 1 : 0];
-        hipLaunchKernelGGL(exact, dim3(ctx->numCUs), dim3(kBlock), 0, ctx->stream, ctx->view, pb, 0, kRetraceStage, 32, ctx->innerShare);
+        hipLaunchKernelGGL(exact, dim3(ctx->numCUs), dim3(kBlock), 0, ctx->stream, ctx->view, pb, 0, stage, 32, ctx->innerShare);
     }
     if (e1) hipEventRecord(e1, ctx->stream);
     if (e0 && e1) ctx->traceEvents.push_back({e0, e1});

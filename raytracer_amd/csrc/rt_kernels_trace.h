@@ -243,12 +243,15 @@ __global__ __launch_bounds__(kBlock, WIDE ? (ALPHA ? RT_WWIDE_ALPHA : RT_WWIDE)
 
     Stage *st = &pb.stages[stage];
     // extParity 0/1: the bounce's extension queue; -1: shadow rays only.  RETRACE instances read the
-    // re-trace list of the four-wide walk instead (one sub-queue, whose count may exceed what was stored).
+    // stage's re-trace list left by the four-wide walk instead (one queue, whose count may exceed what was stored).
     constexpr bool retraceList = RETRACE;   // its own instances, so that the others carry none of it
     const uint32_t *qExt = retraceList ? pb.retrace : extParity >= 0 ? pb.qExt[extParity] : nullptr;
     auto lengthOf = [&](const SubQueue *q) -> uint32_t { return retraceList ? min(q->count, pb.retraceCap) : q->count; };
     const int firstSource = qExt ? 0 : kSubQueues;
-    const int numSources = 2 * kSubQueues - firstSource;
+    const int numSources = retraceList ? 1 : 2 * kSubQueues - firstSource;   // the list is one queue
+    auto queueOf = [&](int src) -> SubQueue * {
+        return retraceList ? &st->retrace : (src < kSubQueues) ? &st->ext[src] : &st->shadow[src - kSubQueues];
+    };
     const uint32_t waveId = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     int source = firstSource + (int)(waveId % (uint32_t)numSources);
     bool drained = false;    // every source has been seen empty
@@ -352,7 +355,7 @@ __global__ __launch_bounds__(kBlock, WIDE ? (ALPHA ? RT_WWIDE_ALPHA : RT_WWIDE)
             // `source` is the same in every lane; saying so keeps the queue header in scalar registers
             // and turns the load of its length into a scalar load.
             const int src = __builtin_amdgcn_readfirstlane(source);
-            SubQueue *sq = (src < kSubQueues) ? &st->ext[src] : &st->shadow[src - kSubQueues];
+            SubQueue *sq = queueOf(src);
             const uint32_t n = lengthOf(sq);
             const int leader = __ffsll((long long)idleMask) - 1;
             uint32_t base = n;
@@ -362,8 +365,8 @@ __global__ __launch_bounds__(kBlock, WIDE ? (ALPHA ? RT_WWIDE_ALPHA : RT_WWIDE)
             }
             if (base >= n) {
                 bool has = false;
-                if ((int)lane >= firstSource && (int)lane < 2 * kSubQueues) {
-                    SubQueue *o = ((int)lane < kSubQueues) ? &st->ext[lane] : &st->shadow[lane - kSubQueues];
+                if ((int)lane >= firstSource && (int)lane < firstSource + numSources) {
+                    SubQueue *o = queueOf((int)lane);
                     has = __hip_atomic_load(&o->cursor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < lengthOf(o);
                 }
                 const unsigned long long live = __ballot(has);
@@ -558,7 +561,7 @@ __global__ __launch_bounds__(kBlock, WIDE ? (ALPHA ? RT_WWIDE_ALPHA : RT_WWIDE)
                     if (WIDE && hasTie(r) && pb.retrace != nullptr) {
                         // Two triangles of one model at the closest distance: the reference's winner is
                         // the one ITS walk meets first, so this ray is traced again in that order.
-                        const uint32_t at = atomicAdd(&pb.stages[kRetraceStage].ext[0].count, 1u);
+                        const uint32_t at = atomicAdd(&st->retrace.count, 1u);
                         if (at < pb.retraceCap) pb.retrace[at] = r.slot;
                     }
                     active = false;
@@ -569,7 +572,7 @@ __global__ __launch_bounds__(kBlock, WIDE ? (ALPHA ? RT_WWIDE_ALPHA : RT_WWIDE)
 
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         if (retraceList) {   // these rays were counted by the first walk; they get a count of their own
-            const uint32_t again = lengthOf(&st->ext[0]);
+            const uint32_t again = lengthOf(&st->retrace);
             if (again != 0u) atomicAdd(&pb.counters[5], (unsigned long long)again);
         } else {
             unsigned long long total = 0;

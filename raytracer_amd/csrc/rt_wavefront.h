@@ -93,6 +93,7 @@ struct __attribute__((aligned(128))) SubQueue {
 struct Stage {
     SubQueue ext[kSubQueues];      // extension rays entering this bounce
     SubQueue shadow[kSubQueues];   // shadow rays produced by the previous bounce
+    SubQueue retrace;              // rays of this stage to be traced again in the reference's order (PathBuffers::retrace)
 };
 
 struct PathBuffers {
@@ -104,18 +105,17 @@ struct PathBuffers {
     uint32_t *qExt[2];   // [kSubQueues * subCap] each, ping-pong by bounce parity
     uint32_t *qShadow;   // [kSubQueues * subCap]
     uint32_t subCap;     // capacity of one sub-queue
-    Stage *stages;       // [kMaxBounces + 3]: one per bounce, the last shadow stage, the re-trace stage
+    Stage *stages;       // [kMaxBounces + 2]: one per bounce and the last shadow stage
     unsigned long long *counters;  // [8]: 0 rays, 1 nodeVisits, 2 triTests, 3 shadedHits, 4 deepest traversal stack
     // Four-wide traversal only: stack entries beyond the LDS part, [wave][overflowDepth][64].
     int32_t *overflow;
     uint32_t overflowDepth;
     // Four-wide traversal with exact ties: slots of rays that met two triangles of one model at the
     // same distance; they are traced again in the reference's visiting order.  The count is
-    // stages[kRetraceStage].ext[0].count (it may exceed the capacity: the surplus is not stored).
+    // stage's retrace.count (it may exceed the capacity: the surplus is not stored).
     uint32_t *retrace;
     uint32_t retraceCap;
 };
-constexpr int kRetraceStage = kMaxBounces + 2;
 
 __device__ __forceinline__ uint32_t laneId() { return threadIdx.x & 63u; }
 // The lane number from the execution-mask counters; volatile, so every use re-reads it.
