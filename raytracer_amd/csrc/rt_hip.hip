@@ -39,6 +39,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -430,7 +431,14 @@ bool sahTree(const std::vector<float> &mdl, const ModelDesc &d, const std::vecto
     auto forked = [](int parts, int lo, int hi, auto fn) {
         const long long count = hi - lo;
         std::vector<std::thread> pool;
-        for (int t = 1; t < parts; ++t) pool.emplace_back(fn, t, lo + (int)(count * t / parts), lo + (int)(count * (t + 1) / parts));
+        for (int t = 1; t < parts; ++t) {
+            const int a = lo + (int)(count * t / parts), b = lo + (int)(count * (t + 1) / parts);
+            try {
+                pool.emplace_back(fn, t, a, b);
+            } catch (const std::system_error &) {
+                fn(t, a, b);   // no thread to be had: do the piece here
+            }
+        }
         fn(0, lo, lo + (int)(count / parts));
         for (std::thread &th : pool) th.join();
     };
@@ -582,7 +590,13 @@ bool sahTree(const std::vector<float> &mdl, const ModelDesc &d, const std::vecto
                 build(later[k].lo, later[k].hi, later[k].depth, parts[k], 0, nullptr);
         };
         std::vector<std::thread> pool;
-        for (int w = 1; w < workers; ++w) pool.emplace_back(work);
+        for (int w = 1; w < workers; ++w) {
+            try {
+                pool.emplace_back(work);
+            } catch (const std::system_error &) {
+                break;   // the threads that did start, and this one, share the ranges
+            }
+        }
         work();
         for (std::thread &th : pool) th.join();
         for (size_t k = 0; k < later.size(); ++k) {
@@ -994,6 +1008,18 @@ void closeComm(rt_ctx *ctx) {
     ctx->commWorld = 1;
 }
 
+// Host allocations of the calls that copy or re-pack whole scenes must not leave the C boundary as exceptions.
+template <typename Body>
+int noThrow(Body body) {
+    try {
+        return body();
+    } catch (const std::bad_alloc &) {
+        return RT_ERR_NOMEM;
+    } catch (...) {
+        return RT_ERR_INVALID;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -1107,13 +1133,19 @@ void rt_destroy(rt_ctx *ctx) {
 int rt_upload(rt_ctx *ctx, int slot, const void *data, size_t bytes) {
     if (ctx == nullptr || slot < 1 || slot > 5 || (data == nullptr && bytes != 0) || (bytes % 4) != 0) return RT_ERR_INVALID;
     const float *w = static_cast<const float *>(data);
-    ctx->host[slot].assign(w, w + bytes / 4);
+    const int rc = noThrow([&]() -> int { ctx->host[slot].assign(w, w + bytes / 4); return RT_OK; });
+    if (rc != RT_OK) return rc;
     ctx->dirty = true;
     ctx->committed = false;
     return RT_OK;
 }
 
+static int commitScene(rt_ctx *ctx, int objectCount, int modelsCount, int lightSourcesCount);
 int rt_commit_scene(rt_ctx *ctx, int objectCount, int modelsCount, int lightSourcesCount) {
+    return noThrow([&]() -> int { return commitScene(ctx, objectCount, modelsCount, lightSourcesCount); });
+}
+
+static int commitScene(rt_ctx *ctx, int objectCount, int modelsCount, int lightSourcesCount) {
     if (ctx == nullptr || objectCount < 0 || modelsCount < 0 || lightSourcesCount < 0) return RT_ERR_INVALID;
     if (ctx->committed && !ctx->dirty && objectCount == ctx->objectCount && modelsCount == ctx->modelsCount &&
         lightSourcesCount == ctx->lightSourcesCount)
