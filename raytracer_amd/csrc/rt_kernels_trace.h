@@ -217,7 +217,9 @@ __device__ __forceinline__ void intersectPrimitives(const SceneView &sc, LaneRay
 // WIDE variants walk the models' four-wide trees instead: half as many dependent node loads per
 // ray.  They find the same closest hit (the later model winning a tie between models, as in the
 // reference), but not by the reference's visiting order, so between two triangles of one model at
-// the same distance the other one may win.  (One tree over all models was tried: fewer nodes per
+// the same distance the other one may win: a ray that meets such a tie is marked and, when the
+// caller passes a re-trace list, appended to it for a second walk by a RETRACE instance (reference
+// order over the uploaded trees), which overwrites its hit record.  (One tree over all models was tried: fewer nodes per
 // ray but slower, because lanes then mix the small models' leaves with the large model's inner
 // nodes and the two phases of the loop run emptier.)
 template <bool COUNT, int STACK, bool ALPHA, bool PRIMS, bool ROOTS, bool WIDE, bool RETRACE = false>
