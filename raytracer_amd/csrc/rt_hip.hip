@@ -713,9 +713,12 @@ int buildWideNodes(rt_ctx *ctx, std::vector<ModelDesc> &descs, std::vector<WideN
     };
     struct Item { int32_t node; int32_t wide; int held; };   // binary node to expand, its slot, entries its ancestors keep stacked
     std::vector<Item> todo;
+    struct Family { int32_t kids[4]; int count; };   // the binary nodes a wide node's children stand for
+    std::vector<Family> families(wnodes.size());
     for (auto &rootOf : roots) {
         rootOf.second->wideRootRef = (int32_t)wnodes.size();
         wnodes.emplace_back();
+        families.emplace_back();
         todo.push_back({rootOf.first, rootOf.second->wideRootRef, 0});
     }
     while (!todo.empty()) {
@@ -741,69 +744,99 @@ int buildWideNodes(rt_ctx *ctx, std::vector<ModelDesc> &descs, std::vector<WideN
         for (int i = 0; i < nk; ++i)
             if (!(bin[(size_t)kids[i]].leaf && leafCount(kids[i]) == 0)) kids[kept++] = kids[i];
         nk = kept;
-        for (int i = 0; i < nk; ++i)
-            for (int w = 0; w < 6; ++w)
-                if (!(std::fabs(bin[(size_t)kids[i]].box[w]) <= 1e15f)) return RT_ERR_SCENE;
-
-        WideNode wn{};
-        for (int a = 0; a < 3; ++a) {
-            double lower = 0.0, upper = 0.0;
-            for (int i = 0; i < nk; ++i) {
-                const double mn = bin[(size_t)kids[i]].box[a], mx = bin[(size_t)kids[i]].box[3 + a];
-                if (mn > mx) return RT_ERR_SCENE;
-                if (i == 0 || mn < lower) lower = mn;
-                if (i == 0 || mx > upper) upper = mx;
-            }
-            float o = (float)(lower - pad);
-            if ((double)o > lower - pad) o = std::nextafterf(o, -INFINITY);
-            const double extent = (upper + pad) - (double)o;
-            int e = -60;
-            if (extent > 0.0) e = std::max(-60, (int)std::ceil(std::log2(extent / 255.0)));
-            for (;; ++e) {
-                const double step = std::ldexp(1.0, e);
-                bool fits = true;
-                uint32_t wlo = 0, whi = 0;
-                for (int i = 0; i < 4 && fits; ++i) {
-                    uint32_t qlo = 255, qhi = 0;   // unused slot: inverted
-                    if (i < nk) {
-                        const double mn = (double)bin[(size_t)kids[i]].box[a] - pad, mx = (double)bin[(size_t)kids[i]].box[3 + a] + pad;
-                        long ql = (long)std::floor((mn - (double)o) / step), qh = (long)std::ceil((mx - (double)o) / step);
-                        ql = std::max(0l, std::min(ql, 255l));
-                        while (ql > 0 && (double)o + (double)ql * step > mn) --ql;
-                        qh = std::max(qh, 0l);
-                        while (qh <= 255 && (double)o + (double)qh * step < mx) ++qh;
-                        if (qh > 255) { fits = false; break; }
-                        qlo = (uint32_t)ql;
-                        qhi = (uint32_t)qh;
-                    }
-                    wlo |= qlo << (8 * i);
-                    whi |= qhi << (8 * i);
-                }
-                if (fits) {
-                    wn.o[a] = o;
-                    wn.s[a] = (float)step;
-                    wn.lo[a] = wlo;
-                    wn.hi[a] = whi;
-                    break;
-                }
-            }
-        }
+        Family fam{{-1, -1, -1, -1}, nk};
         int32_t refs[4] = {-1, -1, -1, -1};   // ~0: a leaf without triangles
         const int held = it.held + std::max(nk - 1, 0);
         ctx->wideStackNeed = std::max(ctx->wideStackNeed, held);
         for (int i = 0; i < nk; ++i) {
+            fam.kids[i] = kids[i];
             if (bin[(size_t)kids[i]].leaf) {
                 refs[i] = bin[(size_t)kids[i]].leafRef;
             } else {
                 refs[i] = (int32_t)wnodes.size();
                 wnodes.emplace_back();
+                families.emplace_back();
                 todo.push_back({kids[i], refs[i], held});
             }
         }
+        WideNode &wn = wnodes[(size_t)it.wide];
         wn.c0 = refs[0]; wn.c1 = refs[1]; wn.c2 = refs[2]; wn.c3 = refs[3];
-        wnodes[(size_t)it.wide] = wn;
+        families[(size_t)it.wide] = fam;
     }
-    commitLap("collapse to four-wide", mark);
+    commitLap("four-wide structure", mark);
+
+    // The child boxes of every node as 8-bit plane numbers: independent per node, shared among threads.
+    std::atomic<bool> bad{false};
+    auto quantise = [&](size_t first, size_t last) {
+        for (size_t w = first; w < last; ++w) {
+            const Family &fam = families[w];
+            const int nk = fam.count;
+            const int32_t *kids = fam.kids;
+            WideNode &wn = wnodes[w];
+            for (int i = 0; i < nk; ++i)
+                for (int k = 0; k < 6; ++k)
+                    if (!(std::fabs(bin[(size_t)kids[i]].box[k]) <= 1e15f)) { bad = true; return; }
+            for (int a = 0; a < 3; ++a) {
+                double lower = 0.0, upper = 0.0;
+                for (int i = 0; i < nk; ++i) {
+                    const double mn = bin[(size_t)kids[i]].box[a], mx = bin[(size_t)kids[i]].box[3 + a];
+                    if (mn > mx) { bad = true; return; }
+                    if (i == 0 || mn < lower) lower = mn;
+                    if (i == 0 || mx > upper) upper = mx;
+                }
+                float o = (float)(lower - pad);
+                if ((double)o > lower - pad) o = std::nextafterf(o, -INFINITY);
+                const double extent = (upper + pad) - (double)o;
+                int e = -60;
+                if (extent > 0.0) e = std::max(-60, (int)std::ceil(std::log2(extent / 255.0)));
+                for (;; ++e) {
+                    const double step = std::ldexp(1.0, e);
+                    bool fits = true;
+                    uint32_t wlo = 0, whi = 0;
+                    for (int i = 0; i < 4 && fits; ++i) {
+                        uint32_t qlo = 255, qhi = 0;   // unused slot: inverted
+                        if (i < nk) {
+                            const double mn = (double)bin[(size_t)kids[i]].box[a] - pad, mx = (double)bin[(size_t)kids[i]].box[3 + a] + pad;
+                            long ql = (long)std::floor((mn - (double)o) / step), qh = (long)std::ceil((mx - (double)o) / step);
+                            ql = std::max(0l, std::min(ql, 255l));
+                            while (ql > 0 && (double)o + (double)ql * step > mn) --ql;
+                            qh = std::max(qh, 0l);
+                            while (qh <= 255 && (double)o + (double)qh * step < mx) ++qh;
+                            if (qh > 255) { fits = false; break; }
+                            qlo = (uint32_t)ql;
+                            qhi = (uint32_t)qh;
+                        }
+                        wlo |= qlo << (8 * i);
+                        whi |= qhi << (8 * i);
+                    }
+                    if (fits) {
+                        wn.o[a] = o;
+                        wn.s[a] = (float)step;
+                        wn.lo[a] = wlo;
+                        wn.hi[a] = whi;
+                        break;
+                    }
+                }
+            }
+        }
+    };
+    {
+        const size_t total = wnodes.size();
+        const int workers = total >= 32768 ? buildThreads() : 1;
+        std::vector<std::thread> pool;
+        for (int t = 1; t < workers; ++t) {
+            const size_t first = total * (size_t)t / (size_t)workers, last = total * (size_t)(t + 1) / (size_t)workers;
+            try {
+                pool.emplace_back(quantise, first, last);
+            } catch (const std::system_error &) {
+                quantise(first, last);
+            }
+        }
+        quantise(0, total / (size_t)workers);
+        for (std::thread &th : pool) th.join();
+    }
+    if (bad) return RT_ERR_SCENE;
+    commitLap("child boxes to 8 bits", mark);
     return RT_OK;
 }
 
