@@ -32,6 +32,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -564,7 +565,16 @@ bool sahTree(const std::vector<float> &mdl, const ModelDesc &d, const std::vecto
                 out[(size_t)self] = n;
                 continue;
             }
-            bounds(it.lo, it.hi, n.box);
+            const int pieces = later != nullptr ? std::max(1, std::min(workers, (it.hi - it.lo) / 8192)) : 1;
+            if (pieces > 1) {   // a long range near the top: the scan is shared, minima and maxima merge exactly
+                std::vector<std::array<float, 6>> partial((size_t)pieces);
+                forked(pieces, it.lo, it.hi, [&](int part, int a, int b) { bounds(a, b, partial[(size_t)part].data()); });
+                for (int k = 0; k < 3; ++k) { n.box[k] = INFINITY; n.box[3 + k] = -INFINITY; }
+                for (const auto &pbox : partial)
+                    for (int k = 0; k < 3; ++k) { n.box[k] = std::min(n.box[k], pbox[(size_t)k]); n.box[3 + k] = std::max(n.box[3 + k], pbox[(size_t)(3 + k)]); }
+            } else {
+                bounds(it.lo, it.hi, n.box);
+            }
             const int mid = split(it.lo, it.hi, it.depth, later != nullptr);
             out[(size_t)self] = n;
             if (mid > 0) {
