@@ -595,9 +595,14 @@ bool sahTree(const std::vector<float> &mdl, const ModelDesc &d, const std::vecto
         build(0, T, 0, nodes, std::max(T / (workers * 4), 8192), &later);
         std::vector<std::vector<Node>> parts(later.size());
         std::atomic<size_t> next{0};
+        std::atomic<bool> failed{false};   // an allocation failure must not end the process from inside a thread
         auto work = [&]() {
-            for (size_t k = next.fetch_add(1); k < later.size(); k = next.fetch_add(1))
-                build(later[k].lo, later[k].hi, later[k].depth, parts[k], 0, nullptr);
+            try {
+                for (size_t k = next.fetch_add(1); k < later.size(); k = next.fetch_add(1))
+                    build(later[k].lo, later[k].hi, later[k].depth, parts[k], 0, nullptr);
+            } catch (...) {
+                failed = true;
+            }
         };
         std::vector<std::thread> pool;
         for (int w = 1; w < workers; ++w) {
@@ -609,6 +614,7 @@ bool sahTree(const std::vector<float> &mdl, const ModelDesc &d, const std::vecto
         }
         work();
         for (std::thread &th : pool) th.join();
+        if (failed) throw std::bad_alloc();   // reported as RT_ERR_NOMEM by the caller
         for (size_t k = 0; k < later.size(); ++k) {
             // the part's root takes the place of the node that stood for the range; the rest is appended
             const int32_t shift = (int32_t)nodes.size() - 1;
