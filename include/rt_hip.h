@@ -113,6 +113,16 @@ int rt_readback(rt_ctx *ctx, float *rgba_sum, size_t floats, uint32_t *frames);
  * Writes W*H RGBA8 pixels (row 0 = bottom row).  Synchronises. */
 int rt_display_rgba8(rt_ctx *ctx, uint8_t *rgba8, size_t bytes);
 
+/* rt_display_rgba8 for callers that cannot allocate (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same result, but the
+ * RGBA8 frame is staged in a fixed 32 MiB array that every GPU the library runs on holds until the
+ * process ends, instead of a buffer allocated per call: no hipMalloc/hipFree happens here.  Frames
+ * of more than 8,388,608 pixels (3840x2160 fits) are refused with RT_ERR_INVALID and a message in
+ * rt_last_hip_error.  `rgba8` may be host memory (pinned memory keeps the runtime's own copy path
+ * free of staging) or device memory.  All contexts on one GPU share the array: calls that overlap
+ * on one GPU race.  Synchronises. */
+int rt_display_rgba8_noalloc(rt_ctx *ctx, uint8_t *rgba8, size_t bytes);
+
 /* Checkpoint/resume of the progressive state (no reference counterpart: the reference keeps
  * it only in two GPU textures and m_frameCount, src/RayTracer.h:24-27): uploads a sum buffer
  * previously obtained from rt_readback together with its frame count. */

@@ -23,7 +23,7 @@ RT_OPT_STRATIFIED = 10
 # Every symbol include/rt_hip.h declares.
 HIP_SYMBOLS = [
     "rt_create", "rt_destroy", "rt_upload", "rt_commit_scene", "rt_resize", "rt_set_frame", "rt_render",
-    "rt_reset_accum", "rt_sync", "rt_readback", "rt_display_rgba8", "rt_restore_accum", "rt_accum_device_ptr", "rt_bind_accum", "rt_add_frames",
+    "rt_reset_accum", "rt_sync", "rt_readback", "rt_display_rgba8", "rt_display_rgba8_noalloc", "rt_restore_accum", "rt_accum_device_ptr", "rt_bind_accum", "rt_add_frames",
     "rt_trace_primary", "rt_get_stats", "rt_reset_stats", "rt_set_counters", "rt_set_option", "rt_set_tile_shard", "rt_strerror", "rt_last_hip_error",
     "rt_comm_unique_id", "rt_comm_init", "rt_reduce",
 ]
@@ -92,6 +92,7 @@ hip.rt_reset_accum.argtypes = [_vp]
 hip.rt_sync.argtypes = [_vp]
 hip.rt_readback.argtypes = [_vp, _vp, _sz, C.POINTER(_u32)]
 hip.rt_display_rgba8.argtypes = [_vp, _vp, _sz]
+hip.rt_display_rgba8_noalloc.argtypes = [_vp, _vp, _sz]
 hip.rt_restore_accum.argtypes = [_vp, _vp, _sz, _u32]
 hip.rt_accum_device_ptr.argtypes = [_vp, C.POINTER(_vp), C.POINTER(_sz)]
 hip.rt_bind_accum.argtypes = [_vp, _vp, _sz]
@@ -252,6 +253,12 @@ class Backend:
     def display_rgba8(self):
         out = np.empty((self.height, self.width, 4), dtype=np.uint8)
         self._check(hip.rt_display_rgba8(self._ctx, out.ctypes.data_as(_vp), out.size))
+        return out
+
+    def display_rgba8_noalloc(self):
+        """The display pass through the library's fixed staging area (no device allocation in the call)."""
+        out = np.empty((self.height, self.width, 4), dtype=np.uint8)
+        self._check(hip.rt_display_rgba8_noalloc(self._ctx, out.ctypes.data_as(_vp), out.size))
         return out
 
     def restore_accum(self, rgba_sum, frames):

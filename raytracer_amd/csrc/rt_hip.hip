@@ -58,10 +58,18 @@ using namespace rtd;
 // Host side
 // ============================================================================================
 
+// Staging area of rt_display_rgba8_noalloc: the RGBA8 frame between the display kernel and the copy
+// into the caller's buffer.  One copy per GPU, held until the process ends; host code never uses
+// the array's name as an address (it is a host-side stand-in there) but the per-device address
+// obtained with hipGetSymbolAddress in rt_create.
+constexpr size_t kDisplayScratchBytes = 32u << 20;   // 8 Mi pixels: frames up to 3840x2160
+static __device__ __align__(256) unsigned char scratch[kDisplayScratchBytes];
+
 struct rt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     std::string hipError;
+    uchar4 *displayScratch = nullptr;   // this device's copy of `scratch` (hipGetSymbolAddress)
 
     std::vector<float> host[6];     // uploaded words per slot (1..5)
     float *dStream[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -1140,6 +1148,14 @@ int rt_create(rt_ctx **out, int device) {
         delete ctx;
         return RT_ERR_HIP;
     }
+    // Every GPU holds its own copy of the file-scope staging array at its own address.
+    void *scratchPtr = nullptr;
+    if (hipGetSymbolAddress(&scratchPtr, HIP_SYMBOL(scratch)) != hipSuccess || scratchPtr == nullptr) {
+        hipStreamDestroy(ctx->stream);
+        delete ctx;
+        return RT_ERR_HIP;
+    }
+    ctx->displayScratch = static_cast<uchar4 *>(scratchPtr);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ctx->numCUs = prop.multiProcessorCount;
     if (const char *env = std::getenv("RT_MAX_PATHS")) {
@@ -1449,6 +1465,24 @@ int rt_display_rgba8(rt_ctx *ctx, uint8_t *rgba8, size_t bytes) {
         ctx->hipError = std::string("rt_display_rgba8: ") + hipGetErrorString(e);
         return RT_ERR_HIP;
     }
+    return RT_OK;
+}
+
+int rt_display_rgba8_noalloc(rt_ctx *ctx, uint8_t *rgba8, size_t bytes) {
+    if (ctx == nullptr || rgba8 == nullptr) return RT_ERR_INVALID;
+    if (ctx->dAccum == nullptr) return RT_ERR_STATE;
+    const size_t px = (size_t)ctx->W * ctx->H;
+    if (bytes != px * 4) return RT_ERR_INVALID;
+    if (bytes > kDisplayScratchBytes) {
+        ctx->hipError = "rt_display_rgba8_noalloc: a frame of " + std::to_string(px) + " pixels does not fit the fixed staging area of " +
+                        std::to_string(kDisplayScratchBytes / 4) + " pixels (use rt_display_rgba8)";
+        return RT_ERR_INVALID;
+    }
+    RT_HIP(hipSetDevice(ctx->device));
+    // The kernel writes every pixel of the frame, so what an earlier call left in the staging area does not matter.
+    hipLaunchKernelGGL(k_display, dim3(gridFor(ctx, px, 8)), dim3(kBlock), 0, ctx->stream, ctx->dAccum, ctx->displayScratch, (uint32_t)px);
+    RT_HIP(hipMemcpyAsync(rgba8, ctx->displayScratch, bytes, hipMemcpyDefault, ctx->stream));
+    RT_HIP(hipStreamSynchronize(ctx->stream));
     return RT_OK;
 }
 
