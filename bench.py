@@ -10,6 +10,11 @@ N > 1: one process per GPU (torch.distributed, backend nccl = RCCL).  The scene
 is replicated; rank r renders frames r+1, r+1+N, ... (sample-split, weak
 scaling: 64 spp per GPU per step) into its own fp32 sum buffer, and the buffers
 are summed onto rank 0 with one RCCL reduce per step inside the timed region.
+Either a launcher provides the ranks (`python -m torch.distributed.run
+--nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py
+--gpus N ...`: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the
+environment), or, when WORLD_SIZE is not set, `python bench.py --gpus N` starts
+the N ranks itself as child processes (the parent never touches a GPU).
 
 Prints ONE JSON line on rank 0.
 """
@@ -61,11 +66,47 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-optin", action="store_true", help="skip the informational figures for the other settings of RT_OPT_WIDE_BVH")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
+    ap.add_argument("--dump-accum", default=None, help="rank 0 saves the merged fp32 sum buffer of the timed steps to this .npy file")
     return ap.parse_args()
+
+
+def launch_ranks(args):
+    """`--gpus N` with no launcher around: start the N ranks of this script as child processes and
+    wait for them.  Runs before anything in this process has touched a GPU (torch is not even
+    imported yet); rank 0's JSON line goes to this process's stdout."""
+    import socket
+    import subprocess
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs between processes here
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    pending = list(procs)
+    while pending:
+        for p in list(pending):
+            code = p.poll()
+            if code is None:
+                continue
+            pending.remove(p)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 128 - code
+                for q in pending:   # a rank that died leaves the others waiting in a collective
+                    q.terminate()
+        time.sleep(0.05)
+    return rc
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args))
     import torch
     import torch.distributed as dist
 
@@ -78,6 +119,8 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP backend has no CPU fallback")
     torch.cuda.set_device(local_rank)
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started {world} ranks; measuring {world}", file=sys.stderr)
     distributed = world > 1
     if distributed:
         if args.dist_backend == "nccl":
@@ -157,6 +200,14 @@ def main():
     elapsed = time.perf_counter() - t0
 
     st = be.stats()
+    devices = [f"rank {rank}: cuda:{local_rank} {torch.cuda.get_device_name(local_rank)}"]
+    if distributed:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, devices[0])
+        devices = gathered
+    if args.dump_accum and rank == 0:
+        import numpy as np
+        np.save(args.dump_accum, accum.cpu().numpy())
     local = torch.tensor([elapsed, float(st["rays"]), float(st["camera_samples"]), st["trace_ms"], float(st["trace_launches"])],
                          dtype=torch.float64, device=f"cuda:{local_rank}")
     if distributed:
@@ -185,7 +236,7 @@ def main():
             "metric": "Mrays/s",
             "value": round(mrays, 3),
             "unit": "Mrays/s",
-            "n_gpus": world,
+            "n_gpus": dist.get_world_size() if distributed else 1,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
@@ -223,6 +274,9 @@ def main():
                 "trace_fraction_of_step": round(st["trace_ms"] / max(st["total_ms"], 1e-9), 4),
                 "trace_only_mrays_per_s": round(st["rays"] / max(trace_s, 1e-12) / 1e6, 2),
             },
+            "devices": devices,
+            "comm": ({"backend": "rccl" if dist.get_backend() == "nccl" else dist.get_backend(), "ranks": dist.get_world_size(),
+                      "collective": "one reduce(SUM) of the fp32 sum buffer per step, %d bytes" % (accum.numel() * 4)} if distributed else None),
             "host_scene_build_s": round(t_build, 2),
             "scene_upload_commit_s": round(t_commit, 2),
         }

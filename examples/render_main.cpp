@@ -92,6 +92,10 @@ int main(int argc, char **argv) {
     // Backend switch with no counterpart in the reference: which trees the rays walk.
     if (wide >= 0 && rt_set_option(rayEngine.getRayTracer().backend(), RT_OPT_WIDE_BVH, wide) != RT_OK) return 1;
     rayEngine.render(static_cast<u32>(frames));   // accumulate
+    if (rayEngine.getRayTracer().status() != RT_OK) {
+        std::fprintf(stderr, "render failed: %s\n", rt_strerror(rayEngine.getRayTracer().status()));
+        return 1;
+    }
 
     rt_ctx *ctx = rayEngine.getRayTracer().backend();
     std::vector<uint8_t> rgba8(static_cast<size_t>(width) * height * 4);

@@ -81,7 +81,10 @@ int rt_upload(rt_ctx *ctx, int slot, const void *data, size_t bytes);
 
 /* RayScene::bindShader + the scene uniforms (src/RayScene.cpp:30-52,
  * src/RayTracer.cpp:1436-1437): fixes the counts and re-packs the uploaded
- * streams into the traversal layout (64-byte inner nodes, 48-byte triangles). */
+ * streams into the traversal layout (64-byte inner nodes, 48-byte triangles).  Every offset the
+ * kernels follow is validated first (RT_ERR_SCENE otherwise): sections inside their streams, vertex /
+ * material / texture references in range, trees at most 32 levels deep with children after their
+ * parent and one parent per node, leaves of at most 3 triangles, fewer than 2^29 triangles in all. */
 int rt_commit_scene(rt_ctx *ctx, int objectCount, int modelsCount, int lightSourcesCount);
 
 /* RayTracer::initialize / changeResolution frame textures
@@ -159,6 +162,14 @@ int rt_set_tile_shard(rt_ctx *ctx, uint32_t offset, uint32_t stride);
  * hitTriangle computes them (src/RayScene.cpp:540-544).  Host arrays of W*H. */
 int rt_trace_primary(rt_ctx *ctx, uint32_t frame, int32_t *model, int32_t *ident,
                      float *t, float *u, float *v);
+
+/* Parity hook (no reference counterpart): evaluates the Spectral integrator's colour functions on the
+ * device exactly as the kernels use them, `items` inputs at a time (host arrays).  fn 0: get_cie_xyz
+ * (src/RayTracer.cpp:871-891), in = lambda, out = xyz; fn 1: smits_eval (:920-934), in = lambda,
+ * spectrum type, out = value; fn 2: get_reflectance (:936-978), in = lambda, r, g, b, out = value;
+ * fn 3: xyz_to_rgb(chromatic_adapt_E_to_D65(xyz)) (:1297-1315), in = xyz, out = rgb; fn 4: the tables
+ * the kernels read, CIE x, y, z (41 each) then the 70 Smits values, 193 floats per item, `in` unused. */
+int rt_eval_colour(rt_ctx *ctx, int fn, const float *in, size_t items, float *out);
 
 int rt_get_stats(rt_ctx *ctx, rt_stats *out);
 int rt_reset_stats(rt_ctx *ctx);

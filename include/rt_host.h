@@ -43,6 +43,9 @@ int rth_camera_make(rt_camera *out, const float position[3], float yaw, float pi
 rth_engine *rth_engine_create(const char *scene_name, const int32_t *iparams, int n_iparams,
                               const float position[3], float yaw, float pitch, float fov,
                               int width, int height, int bounces, int rayPerPixel, int type, int device);
+/* RayEngine::render(frames).  0, or the rt_status the backend returned (device out of memory, a scene or
+ * camera it refuses ...): the host layer hands the code on instead of trapping.  No entry point
+ * here lets a C++ exception out; allocation failures read RT_ERR_NOMEM or a NULL handle. */
 int rth_engine_render(rth_engine *engine, int frames);
 /* Progressive mean, width*height*4 floats; returns frames rendered so far or < 0. */
 int rth_engine_frame(rth_engine *engine, float *rgba, size_t floats);

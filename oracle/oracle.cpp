@@ -1149,6 +1149,26 @@ float orc_math(int fn, float x, float y) {
         default: return rtm::sqrt_(x);
     }
 }
+// Colour science of the Spectral integrator, evaluated item by item (same numbering as the
+// backend's rt_eval_colour): 0 get_cie_xyz(lambda) -> xyz; 1 smits_eval(lambda, type) -> value;
+// 2 get_reflectance(lambda, rgb) -> value; 3 xyz_to_rgb(chromatic_adapt_E_to_D65(xyz)) -> rgb;
+// 4 the tables themselves, CIE_X, CIE_Y, CIE_Z (41 each) then SMITS_TABLE (70), per item.
+int orc_eval_colour(int fn, const float *in, size_t items, float *out) {
+    for (size_t i = 0; i < items; ++i) {
+        switch (fn) {
+            case 0: { V3 r = get_cie_xyz(in[i]); out[3 * i] = r.x; out[3 * i + 1] = r.y; out[3 * i + 2] = r.z; break; }
+            case 1: out[i] = smits_eval(in[2 * i], (int)in[2 * i + 1]); break;
+            case 2: out[i] = get_reflectance(in[4 * i], v3(in[4 * i + 1], in[4 * i + 2], in[4 * i + 3])); break;
+            case 3: { V3 r = xyz_to_rgb(chromatic_adapt_E_to_D65(v3(in[3 * i], in[3 * i + 1], in[3 * i + 2]))); out[3 * i] = r.x; out[3 * i + 1] = r.y; out[3 * i + 2] = r.z; break; }
+            case 4:
+                for (int k = 0; k < 41; ++k) { out[193 * i + k] = CIE_X[k]; out[193 * i + 41 + k] = CIE_Y[k]; out[193 * i + 82 + k] = CIE_Z[k]; }
+                for (int k = 0; k < 70; ++k) out[193 * i + 123 + k] = SMITS_TABLE[k];
+                break;
+            default: return -1;
+        }
+    }
+    return 0;
+}
 // Camera ray of pixel (px,py), frame, sample 0: out[0..2] origin, out[3..5] direction.
 int orc_camera_ray(const Camera *cam, int px, int py, uint32_t frame, float out[6]) {
     int ssq = (int)rtm::sqrt_((float)cam->rayPerPixel);

@@ -24,7 +24,7 @@ RT_OPT_STRATIFIED = 10
 HIP_SYMBOLS = [
     "rt_create", "rt_destroy", "rt_upload", "rt_commit_scene", "rt_resize", "rt_set_frame", "rt_render",
     "rt_reset_accum", "rt_sync", "rt_readback", "rt_display_rgba8", "rt_display_rgba8_noalloc", "rt_restore_accum", "rt_accum_device_ptr", "rt_bind_accum", "rt_add_frames",
-    "rt_trace_primary", "rt_get_stats", "rt_reset_stats", "rt_set_counters", "rt_set_option", "rt_set_tile_shard", "rt_strerror", "rt_last_hip_error",
+    "rt_trace_primary", "rt_eval_colour", "rt_get_stats", "rt_reset_stats", "rt_set_counters", "rt_set_option", "rt_set_tile_shard", "rt_strerror", "rt_last_hip_error",
     "rt_comm_unique_id", "rt_comm_init", "rt_reduce",
 ]
 # Every symbol include/rt_host.h declares.
@@ -98,6 +98,7 @@ hip.rt_accum_device_ptr.argtypes = [_vp, C.POINTER(_vp), C.POINTER(_sz)]
 hip.rt_bind_accum.argtypes = [_vp, _vp, _sz]
 hip.rt_add_frames.argtypes = [_vp, _u32]
 hip.rt_trace_primary.argtypes = [_vp, _u32, _vp, _vp, _vp, _vp, _vp]
+hip.rt_eval_colour.argtypes = [_vp, _i, _vp, _sz, _vp]
 hip.rt_get_stats.argtypes = [_vp, C.POINTER(RtStats)]
 hip.rt_reset_stats.argtypes = [_vp]
 hip.rt_set_counters.argtypes = [_vp, _i]
@@ -284,6 +285,17 @@ class Backend:
         self._check(hip.rt_trace_primary(self._ctx, frame, *(a.ctypes.data_as(_vp) for a in (model, ident, t, u, v))))
         shape = (self.height, self.width)
         return model.reshape(shape), ident.reshape(shape), t.reshape(shape), u.reshape(shape), v.reshape(shape)
+
+    def eval_colour(self, fn, values=None, items=1):
+        """Parity hook: the device's colour functions/tables (rt_eval_colour) on rows of inputs."""
+        width_out = (3, 1, 1, 3, 193)[fn]
+        a = None
+        if values is not None:
+            a = np.ascontiguousarray(values, dtype=np.float32)
+            items = a.shape[0] if a.ndim > 1 else a.size
+        out = np.empty((items, width_out), np.float32)
+        self._check(hip.rt_eval_colour(self._ctx, fn, a.ctypes.data_as(_vp) if a is not None else None, items, out.ctypes.data_as(_vp)))
+        return out
 
     def stats(self):
         s = RtStats()

@@ -256,11 +256,18 @@ int repackScene(rt_ctx *ctx, std::vector<PackedNode> &nodes, std::vector<PackedT
         d.lightBase = f2i(info[(size_t)m * 4 + 3]);
         if (d.identifiersCount < 0 || d.lightSourcesCount < 0 || d.nodesCount < 0 || d.lightBase < 0) return RT_ERR_SCENE;
         if (m < ctx->lightSourcesCount && d.lightSourcesCount <= 0) return RT_ERR_SCENE;  // light models come first
-        d.nodeBase = d.lightBase + d.lightSourcesCount * kIdentWords;
-        d.identBase = d.nodeBase + d.nodesCount * kNodeWords;
-        d.vertBase = d.identBase + d.identifiersCount * kIdentWords;
+        // Section ends in 64 bits: counts are caller data, and a product such as identifiersCount * 5
+        // must not wrap into a small offset that passes the range test.
+        const int64_t nodeBase = (int64_t)d.lightBase + (int64_t)d.lightSourcesCount * kIdentWords;
+        const int64_t identBase = nodeBase + (int64_t)d.nodesCount * kNodeWords;
+        const int64_t vertBase = identBase + (int64_t)d.identifiersCount * kIdentWords;
+        if (vertBase > (int64_t)mdl.size() || vertBase > 0x7fffffff) return RT_ERR_SCENE;   // every section lies inside the stream
+        d.nodeBase = (int32_t)nodeBase;
+        d.identBase = (int32_t)identBase;
+        d.vertBase = (int32_t)vertBase;
         d.triBase = (int32_t)tris.size();
-        if ((size_t)d.vertBase > mdl.size()) return RT_ERR_SCENE;
+        // Leaf references keep the triangle index in 29 bits below the sign.
+        if (tris.size() + (size_t)d.identifiersCount >= (1u << 29)) return RT_ERR_SCENE;
         const int vertexCapacity = (int)((mdl.size() - (size_t)d.vertBase) / 8);
 
         auto checkIdent = [&](int wordAt) -> bool {
@@ -340,11 +347,16 @@ int repackScene(rt_ctx *ctx, std::vector<PackedNode> &nodes, std::vector<PackedT
             return true;
         };
         nodes.resize((size_t)innerBase + (size_t)innerCount);
+        // A tree, not a graph: children come after their parent (no cycles) and every node has at
+        // most one parent (a node shared by two parents would make a 32-level graph 2^32 nodes
+        // large for anything that walks it as a tree).
+        std::vector<char> hasParent((size_t)d.nodesCount, 0);
         for (int n = 0; n < d.nodesCount; ++n) {
             if (nodeWord(n, 8) != 0.0f) continue;
             int l = f2i(nodeWord(n, 6)), r = f2i(nodeWord(n, 7));
-            // Children must come after their parent (pre-order layout): rules out cycles.
-            if (l <= n || r <= n) return RT_ERR_SCENE;
+            if (l <= n || r <= n || l >= d.nodesCount || r >= d.nodesCount || l == r) return RT_ERR_SCENE;
+            if (hasParent[(size_t)l] || hasParent[(size_t)r]) return RT_ERR_SCENE;
+            hasParent[(size_t)l] = hasParent[(size_t)r] = 1;
             PackedNode pn{};
             if (!childRef(l, pn.left) || !childRef(r, pn.right)) return RT_ERR_SCENE;
             for (int k = 0; k < 3; ++k) {
@@ -373,7 +385,6 @@ int repackScene(rt_ctx *ctx, std::vector<PackedNode> &nodes, std::vector<PackedT
         }
         descs[(size_t)m] = d;
     }
-    if (tris.size() > (size_t)kIndexMask) return RT_ERR_SCENE;
     return RT_OK;
 }
 
@@ -390,6 +401,28 @@ int buildThreads() {
     if (const char *env = std::getenv("RT_BUILD_THREADS")) return std::min(std::max(std::atoi(env), 1), 64);
     return (int)std::min(std::max(std::thread::hardware_concurrency(), 1u), 16u);
 }
+
+// Joins every thread it holds when it goes out of scope, so that an exception thrown while threads
+// are running (an allocation failure in the spawning loop or in the caller's own share of the work)
+// unwinds past joined threads instead of ending the process in ~thread.
+struct ThreadGroup {
+    std::vector<std::thread> threads;
+    explicit ThreadGroup(size_t expected) { threads.reserve(expected); }
+    ~ThreadGroup() { join(); }
+    void join() {
+        for (std::thread &t : threads)
+            if (t.joinable()) t.join();
+    }
+    // False when the system has no thread to give: the caller does that piece itself.
+    template <typename Fn, typename... Args> bool spawn(Fn &&fn, Args &&...args) {
+        try {
+            threads.emplace_back(std::forward<Fn>(fn), std::forward<Args>(args)...);
+            return true;
+        } catch (const std::system_error &) {
+            return false;
+        }
+    }
+};
 
 // Binary tree over one model's triangles by binned surface-area splits (16 bins per axis on the
 // triangle centres), for RT_OPT_WIDE_BVH 2 and 3.  Nodes are emitted (root first) through `emit(box,
@@ -439,17 +472,13 @@ bool sahTree(const std::vector<float> &mdl, const ModelDesc &d, const std::vecto
     // Runs fn(part, a, b) over `parts` equal pieces of [lo, hi), piece 0 on this thread.
     auto forked = [](int parts, int lo, int hi, auto fn) {
         const long long count = hi - lo;
-        std::vector<std::thread> pool;
+        ThreadGroup pool((size_t)parts);
         for (int t = 1; t < parts; ++t) {
             const int a = lo + (int)(count * t / parts), b = lo + (int)(count * (t + 1) / parts);
-            try {
-                pool.emplace_back(fn, t, a, b);
-            } catch (const std::system_error &) {
-                fn(t, a, b);   // no thread to be had: do the piece here
-            }
+            if (!pool.spawn(fn, t, a, b)) fn(t, a, b);   // no thread to be had: do the piece here
         }
         fn(0, lo, lo + (int)(count / parts));
-        for (std::thread &th : pool) th.join();
+        pool.join();
     };
     struct Bins {
         int counts[3][kBins];
@@ -612,16 +641,12 @@ bool sahTree(const std::vector<float> &mdl, const ModelDesc &d, const std::vecto
                 failed = true;
             }
         };
-        std::vector<std::thread> pool;
-        for (int w = 1; w < workers; ++w) {
-            try {
-                pool.emplace_back(work);
-            } catch (const std::system_error &) {
-                break;   // the threads that did start, and this one, share the ranges
-            }
+        {
+            ThreadGroup pool((size_t)workers);
+            for (int w = 1; w < workers; ++w)
+                if (!pool.spawn(work)) break;   // the threads that did start, and this one, share the ranges
+            work();
         }
-        work();
-        for (std::thread &th : pool) th.join();
         if (failed) throw std::bad_alloc();   // reported as RT_ERR_NOMEM by the caller
         for (size_t k = 0; k < later.size(); ++k) {
             // the part's root takes the place of the node that stood for the range; the rest is appended
@@ -847,17 +872,13 @@ int buildWideNodes(rt_ctx *ctx, std::vector<ModelDesc> &descs, std::vector<WideN
     {
         const size_t total = wnodes.size();
         const int workers = total >= 32768 ? buildThreads() : 1;
-        std::vector<std::thread> pool;
+        ThreadGroup pool((size_t)workers);
         for (int t = 1; t < workers; ++t) {
             const size_t first = total * (size_t)t / (size_t)workers, last = total * (size_t)(t + 1) / (size_t)workers;
-            try {
-                pool.emplace_back(quantise, first, last);
-            } catch (const std::system_error &) {
-                quantise(first, last);
-            }
+            if (!pool.spawn(quantise, first, last)) quantise(first, last);
         }
         quantise(0, total / (size_t)workers);
-        for (std::thread &th : pool) th.join();
+        pool.join();
     }
     if (bad) return RT_ERR_SCENE;
     commitLap("child boxes to 8 bits", mark);
@@ -1571,6 +1592,29 @@ int rt_trace_primary(rt_ctx *ctx, uint32_t frame, int32_t *model, int32_t *ident
             u[at] = h.u;
             v[at] = h.v;
         }
+    }
+    return RT_OK;
+}
+
+int rt_eval_colour(rt_ctx *ctx, int fn, const float *in, size_t items, float *out) {
+    static const int inWidth[5] = {1, 2, 4, 3, 0}, outWidth[5] = {3, 1, 1, 3, 193};
+    if (ctx == nullptr || out == nullptr || fn < 0 || fn > 4 || items == 0 || items > (1u << 24) || (in == nullptr && inWidth[fn] != 0)) return RT_ERR_INVALID;
+    RT_HIP(hipSetDevice(ctx->device));
+    float *dIn = nullptr, *dOut = nullptr;
+    const size_t inBytes = std::max<size_t>(items * inWidth[fn], 1) * sizeof(float), outBytes = items * outWidth[fn] * sizeof(float);
+    RT_HIP(hipMalloc(reinterpret_cast<void **>(&dIn), inBytes));
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&dOut), outBytes);
+    if (e == hipSuccess && inWidth[fn] != 0) e = hipMemcpyAsync(dIn, in, items * inWidth[fn] * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_eval_colour, dim3(gridFor(ctx, items, 4)), dim3(kBlock), 0, ctx->stream, fn, dIn, (uint32_t)items, dOut);
+        e = hipMemcpyAsync(out, dOut, outBytes, hipMemcpyDeviceToHost, ctx->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    hipFree(dIn);
+    if (dOut != nullptr) hipFree(dOut);
+    if (e != hipSuccess) {
+        ctx->hipError = std::string("rt_eval_colour: ") + hipGetErrorString(e);
+        return RT_ERR_HIP;
     }
     return RT_OK;
 }

@@ -168,4 +168,27 @@ __global__ __launch_bounds__(kBlock) void k_display(const float4 *accum, uchar4 
     }
 }
 
+// ---- k_eval_colour -----------------------------------------------------------------------
+// Parity hook: the Spectral integrator's colour functions and tables as the kernels see them,
+// evaluated item by item.  fn: 0 cieXYZ(lambda); 1 smitsBasis(lambda, which); 2 reflectanceAt(lambda,
+// rgb); 3 xyzEToLinearSRGB(xyz); 4 the tables (kCieX, kCieY, kCieZ, kSmits: 193 values per item).
+__global__ __launch_bounds__(kBlock) void k_eval_colour(int fn, const float *in, uint32_t items, float *out) {
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < items; i += gridDim.x * kBlock) {
+        if (fn == 0) {
+            const V3 r = cieXYZ(in[i]);
+            out[3 * i] = r.x; out[3 * i + 1] = r.y; out[3 * i + 2] = r.z;
+        } else if (fn == 1) {
+            out[i] = smitsBasis(in[2 * i], (int)in[2 * i + 1]);
+        } else if (fn == 2) {
+            out[i] = reflectanceAt(in[4 * i], v3(in[4 * i + 1], in[4 * i + 2], in[4 * i + 3]));
+        } else if (fn == 3) {
+            const V3 r = xyzEToLinearSRGB(v3(in[3 * i], in[3 * i + 1], in[3 * i + 2]));
+            out[3 * i] = r.x; out[3 * i + 1] = r.y; out[3 * i + 2] = r.z;
+        } else {
+            for (int k = 0; k < 41; ++k) { out[193 * i + k] = kCieX[k]; out[193 * i + 41 + k] = kCieY[k]; out[193 * i + 82 + k] = kCieZ[k]; }
+            for (int k = 0; k < 70; ++k) out[193 * i + 123 + k] = kSmits[k];
+        }
+    }
+}
+
 }  // namespace

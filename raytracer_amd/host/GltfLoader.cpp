@@ -192,7 +192,7 @@ bool decodePngRGBA(const unsigned char *data, size_t size, int &width, int &heig
         }
         at += 12 + len;
     }
-    if (width <= 0 || height <= 0 || bitDepth != 8 || interlace != 0) return false;
+    if (width <= 0 || height <= 0 || width > 16384 || height > 16384 || bitDepth != 8 || interlace != 0) return false;
     int channels = colorType == 0 ? 1 : colorType == 2 ? 3 : colorType == 3 ? 1 : colorType == 4 ? 2 : colorType == 6 ? 4 : 0;
     if (channels == 0) return false;
     const size_t stride = static_cast<size_t>(width) * channels;
@@ -282,6 +282,8 @@ struct AccessorView {
     size_t count = 0;
     size_t stride = 0;       // accessor.ByteStride(view)
     int componentType = 0;
+    int width = 0;           // components per element (SCALAR 1 ... MAT4 16)
+    bool packedFits = false; // `count` tightly packed elements from `data` also lie inside the buffer
     bool ok = false;
 };
 
@@ -302,20 +304,41 @@ int typeCount(const std::string &t) {
     return 0;
 }
 
+// A byte quantity from the file: a finite number in [0, limit], else `bad`.
+size_t byteField(const Json &j, double fallback, size_t limit, bool &bad) {
+    const double v = j.number(fallback);
+    if (!(v >= 0.0) || v > static_cast<double>(limit)) {
+        bad = true;
+        return 0;
+    }
+    return static_cast<size_t>(v);
+}
+
+// The file is the trust boundary: every offset, count and stride is range-checked against the
+// binary chunk before anything is read through the view.
 AccessorView viewOf(const Glb &glb, int accessorIndex) {
     AccessorView v;
+    if (accessorIndex < 0) return v;
     const Json &acc = glb.doc.at("accessors").at(static_cast<size_t>(accessorIndex));
-    if (accessorIndex < 0 || acc.kind != Json::Object) return v;
-    const Json &bv = glb.doc.at("bufferViews").at(static_cast<size_t>(acc.at("bufferView").integer(-1)));
+    if (acc.kind != Json::Object) return v;
+    const int viewIndex = acc.at("bufferView").integer(-1);
+    if (viewIndex < 0) return v;
+    const Json &bv = glb.doc.at("bufferViews").at(static_cast<size_t>(viewIndex));
     if (bv.kind != Json::Object || bv.at("buffer").integer(0) != 0) return v;
-    const size_t offset = static_cast<size_t>(bv.at("byteOffset").number(0)) + static_cast<size_t>(acc.at("byteOffset").number(0));
-    v.count = static_cast<size_t>(acc.at("count").number(0));
+    const size_t size = glb.bin.size();
+    bool bad = false;
+    const size_t viewOffset = byteField(bv.at("byteOffset"), 0, size, bad), accOffset = byteField(acc.at("byteOffset"), 0, size, bad);
+    const size_t viewStride = byteField(bv.at("byteStride"), 0, size, bad);
+    v.count = byteField(acc.at("count"), 0, size, bad);   // an element takes at least one byte
+    if (bad || viewOffset + accOffset > size) return v;
+    const size_t offset = viewOffset + accOffset;
     v.componentType = acc.at("componentType").integer(0);
-    const size_t elem = static_cast<size_t>(componentSize(v.componentType)) * typeCount(acc.at("type").text());
-    const size_t viewStride = static_cast<size_t>(bv.at("byteStride").number(0));
+    v.width = typeCount(acc.at("type").text());
+    const size_t elem = static_cast<size_t>(componentSize(v.componentType)) * static_cast<size_t>(v.width);
     v.stride = viewStride ? viewStride : elem;
-    if (elem == 0 || v.count == 0) return v;
-    if (offset + (v.count - 1) * v.stride + elem > glb.bin.size()) return v;
+    if (elem == 0 || v.count == 0 || elem > size - offset) return v;
+    if (v.count - 1 > (size - offset - elem) / v.stride) return v;
+    v.packedFits = v.count <= (size - offset) / elem;
     v.data = glb.bin.data() + offset;
     v.ok = true;
     return v;
@@ -345,7 +368,8 @@ void appendPrimitive(MeshData &mesh, const Glb &glb, const Json &prim, const glm
     const Json &attrs = prim.at("attributes");
 
     const AccessorView pos = viewOf(glb, attrs.at("POSITION").integer(-1));
-    if (!pos.ok) return;
+    // read below as tightly packed float3, as the reference reads it: anything else is not a position stream
+    if (!pos.ok || pos.componentType != 5126 || pos.width != 3 || !pos.packedFits) return;
     const size_t vertexCount = pos.count;
     const size_t base = mesh.vertices.size();
     mesh.vertices.resize(base + vertexCount);
@@ -354,7 +378,7 @@ void appendPrimitive(MeshData &mesh, const Glb &glb, const Json &prim, const glm
         mesh.vertices[base + i].position = glm::vec3(world * glm::vec4(p[i * 3 + 0], p[i * 3 + 1], p[i * 3 + 2], 1.0f));
 
     const AccessorView nrm = attrs.has("NORMAL") ? viewOf(glb, attrs.at("NORMAL").integer(-1)) : AccessorView();
-    if (nrm.ok && nrm.count >= vertexCount) {
+    if (nrm.ok && nrm.count >= vertexCount && nrm.componentType == 5126 && nrm.width == 3 && nrm.packedFits) {
         const float *n = reinterpret_cast<const float *>(nrm.data);
         for (size_t i = 0; i < vertexCount; ++i)
             mesh.vertices[base + i].normal = glm::normalize(normalMatrix * glm::vec3(n[i * 3 + 0], n[i * 3 + 1], n[i * 3 + 2]));
@@ -363,7 +387,7 @@ void appendPrimitive(MeshData &mesh, const Glb &glb, const Json &prim, const glm
     }
 
     const AccessorView uv = attrs.has("TEXCOORD_0") ? viewOf(glb, attrs.at("TEXCOORD_0").integer(-1)) : AccessorView();
-    if (uv.ok && uv.count >= vertexCount) {
+    if (uv.ok && uv.count >= vertexCount && uv.width >= 2) {
         for (size_t i = 0; i < vertexCount; ++i) {
             const unsigned char *e = uv.data + i * uv.stride;
             glm::vec2 &dst = mesh.vertices[base + i].uv;
@@ -384,7 +408,7 @@ void appendPrimitive(MeshData &mesh, const Glb &glb, const Json &prim, const glm
     const int indicesAccessor = prim.at("indices").integer(-1);
     if (indicesAccessor < 0) return;   // non-indexed primitives contribute vertices but no triangles
     const AccessorView idx = viewOf(glb, indicesAccessor);
-    if (!idx.ok) return;
+    if (!idx.ok || idx.width != 1 || !idx.packedFits || idx.componentType == 5126 || idx.componentType == 5120 || idx.componentType == 5122) return;
     const int material = prim.at("material").integer(-1);
     const int materialIndex = material < 0 ? 0 : material;
     const size_t triangles = idx.count / 3;
@@ -396,8 +420,12 @@ void appendPrimitive(MeshData &mesh, const Glb &glb, const Json &prim, const glm
             const unsigned char *e = idx.data + (t * 3 + k) * static_cast<size_t>(esize);   // tightly packed
             if (esize == 1) v[k] = e[0];
             else if (esize == 2) { u16 h; std::memcpy(&h, e, 2); v[k] = h; }
-            else { u32 w; std::memcpy(&w, e, 4); v[k] = static_cast<int>(w); }
+            else { u32 w; std::memcpy(&w, e, 4); v[k] = w < 0x7fffffffu ? static_cast<int>(w) : -1; }
         }
+        // a triangle that names a vertex the primitive does not have is dropped
+        if (v[0] < 0 || v[1] < 0 || v[2] < 0 || static_cast<size_t>(v[0]) >= vertexCount || static_cast<size_t>(v[1]) >= vertexCount ||
+            static_cast<size_t>(v[2]) >= vertexCount)
+            continue;
         MeshData::Identifier iden;
         iden.index = glm::ivec3(v[0], v[1], v[2]) + glm::ivec3(static_cast<int>(base));
         iden.materialIndex = materialIndex;
@@ -487,8 +515,9 @@ void convertTexture(const Glb &glb, const Json &texture, MeshData::Texture &out)
         return;
     }
     const Json &bv = glb.doc.at("bufferViews").at(static_cast<size_t>(viewIndex));
-    const size_t offset = static_cast<size_t>(bv.at("byteOffset").number(0)), length = static_cast<size_t>(bv.at("byteLength").number(0));
-    if (offset + length > glb.bin.size()) return;
+    bool bad = false;
+    const size_t offset = byteField(bv.at("byteOffset"), 0, glb.bin.size(), bad), length = byteField(bv.at("byteLength"), 0, glb.bin.size(), bad);
+    if (bad || bv.kind != Json::Object || length > glb.bin.size() - offset) return;
     int w = 0, h = 0;
     std::vector<unsigned char> rgba;
     const unsigned char *bytes = glb.bin.data() + offset;
@@ -502,6 +531,7 @@ void convertTexture(const Glb &glb, const Json &texture, MeshData::Texture &out)
         std::cout << "\tImage encoding not supported (8-bit non-interlaced PNG and baseline JPEG are decoded); texture left empty" << std::endl;
         return;
     }
+    if (w <= 0 || h <= 0 || rgba.size() != static_cast<size_t>(w) * static_cast<size_t>(h) * 4) return;
     out.width = w;
     out.height = h;
     out.channels = 4;
@@ -531,7 +561,9 @@ MeshData MeshData::LoadMeshData(std::string modelPath) {
     mesh.materials.reserve(materials.size());
     for (size_t i = 0; i < materials.size(); ++i) mesh.materials.push_back(convertMaterial(materials.at(i)));
     for (auto &id : mesh.identifiers)
-        if (!mesh.materials.empty() && id.materialIndex >= static_cast<i32>(mesh.materials.size())) id.materialIndex = 0;
+        if (id.materialIndex < 0 || (!mesh.materials.empty() && id.materialIndex >= static_cast<i32>(mesh.materials.size()))) id.materialIndex = 0;
+    for (auto &id : mesh.lightIdentifiers)
+        if (id.materialIndex < 0 || (!mesh.materials.empty() && id.materialIndex >= static_cast<i32>(mesh.materials.size()))) id.materialIndex = 0;
     mesh.deriveTextureFlags();
 
     const Json &textures = glb.doc.at("textures");

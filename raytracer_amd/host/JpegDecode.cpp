@@ -231,6 +231,8 @@ bool DecodeJpegRGBA(const unsigned char *data, size_t size, int &width, int &hei
             if (segLen < 6 || seg[0] != 8) { why = "only 8-bit samples are supported"; return false; }
             height = (seg[1] << 8) | seg[2];
             width = (seg[3] << 8) | seg[4];
+            // a header may claim 65535 x 65535; textures beyond 16384 x 16384 are refused, not allocated
+            if (width > 16384 || height > 16384) { why = "image larger than 16384 x 16384"; return false; }
             const int n = seg[5];
             if ((n != 1 && n != 3) || segLen < static_cast<size_t>(6 + 3 * n) || width <= 0 || height <= 0) {
                 why = "only greyscale and YCbCr images are supported";

@@ -29,12 +29,13 @@ void RayScene::initialize(rt_ctx *backend) {
     m_materials.push_back(Material());
 }
 
-void RayScene::bind() const {
-    for (int slot = RT_SLOT_OBJECTS; slot <= RT_SLOT_TEXTURES; ++slot) m_streams[slot].storage->bindToUnit(slot);
-    if (m_backend != nullptr) {
-        int rc = rt_commit_scene(m_backend, static_cast<int>(getObjectsCount()), static_cast<int>(getModelsCount()), lightSourcesCount);
-        ASSERT(rc == RT_OK);
+int RayScene::bind() const {
+    for (int slot = RT_SLOT_OBJECTS; slot <= RT_SLOT_TEXTURES; ++slot) {
+        m_streams[slot].storage->bindToUnit(slot);
+        if (m_streams[slot].storage->status() != RT_OK) return m_streams[slot].storage->status();
     }
+    if (m_backend == nullptr) return RT_OK;
+    return rt_commit_scene(m_backend, static_cast<int>(getObjectsCount()), static_cast<int>(getModelsCount()), lightSourcesCount);
 }
 
 // Stream order and layouts follow reference src/RayScene.cpp:54-101.

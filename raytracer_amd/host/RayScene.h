@@ -50,7 +50,8 @@ public:
     void initialize(rt_ctx *backend = nullptr);
     // Counterpart of bindShader(gl::ShaderProgram&): names the five slots and
     // commits object/model/light counts to the backend.
-    void bind() const;
+    // Returns the backend's status (RT_OK, or the first failing upload / the commit's code).
+    int bind() const;
     // Serialises everything and uploads.  One-shot: the buffers are never cleared.
     void submit();
 

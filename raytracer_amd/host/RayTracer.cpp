@@ -22,13 +22,17 @@ bool RayTracer::initialize(glm::ivec2 resolution, Type type) {
         return false;
     }
     changeResolution(resolution);
-    return true;
+    return m_status == RT_OK;
 }
 
 // Uniform set of reference src/RayTracer.cpp:1436-1451, then the frames.
 void RayTracer::renderToTexture(const RayCamera &camera, const RayScene &scene, u32 frames) {
     if (frames == 0) return;
-    scene.bind();
+    m_status = scene.bind();
+    if (m_status != RT_OK) {
+        std::cout << "scene commit: " << rt_strerror(m_status) << std::endl;
+        return;
+    }
 
     rt_camera cam;
     cam.fov = camera.fov;
@@ -45,10 +49,12 @@ void RayTracer::renderToTexture(const RayCamera &camera, const RayScene &scene, 
 
     const glm::vec3 sky = scene.getLinearSkyColor();
     const float skyv[3] = {sky.x, sky.y, sky.z};
-    int rc = rt_set_frame(m_ctx, &cam, skyv, m_type == Type::RGB ? RT_TYPE_RGB : RT_TYPE_SPECTRAL);
-    ASSERT(rc == RT_OK);
-    rc = rt_render(m_ctx, m_frameCount, frames, 1);
-    ASSERT(rc == RT_OK);
+    m_status = rt_set_frame(m_ctx, &cam, skyv, m_type == Type::RGB ? RT_TYPE_RGB : RT_TYPE_SPECTRAL);
+    if (m_status == RT_OK) m_status = rt_render(m_ctx, m_frameCount, frames, 1);
+    if (m_status != RT_OK) {   // nothing was rendered: the frame counter stays where it is
+        std::cout << "render: " << rt_strerror(m_status) << " " << rt_last_hip_error(m_ctx) << std::endl;
+        return;
+    }
 
     if (frames & 1u) m_frameIndex = !m_frameIndex;
     m_frameCount += frames;
@@ -61,8 +67,7 @@ void RayTracer::changeResolution(glm::ivec2 resolution) {
     m_frame.height = resolution.y;
     m_frame.rgba.assign(static_cast<size_t>(resolution.x) * resolution.y * 4, 0.0f);
     if (m_ctx != nullptr) {
-        int rc = rt_resize(m_ctx, resolution.x, resolution.y);
-        ASSERT(rc == RT_OK);
+        m_status = rt_resize(m_ctx, resolution.x, resolution.y);
     }
 }
 
@@ -74,8 +79,11 @@ void RayTracer::reset() {
 
 RayFrame &RayTracer::getCurrentFrame() {
     u32 frames = 0;
-    int rc = rt_readback(m_ctx, m_frame.rgba.data(), m_frame.rgba.size(), &frames);
-    ASSERT(rc == RT_OK);
+    m_status = rt_readback(m_ctx, m_frame.rgba.data(), m_frame.rgba.size(), &frames);
+    if (m_status != RT_OK) {
+        m_frame.rgba.assign(m_frame.rgba.size(), 0.0f);
+        return m_frame;
+    }
     if (frames > 0) {
         const f32 n = static_cast<f32>(frames);
         for (size_t i = 0; i < m_frame.rgba.size(); i += 4) {

@@ -30,6 +30,7 @@ private:
     i32 m_frameIndex = 0;
     Type m_type = Type::RGB;
     int m_device = 0;
+    int m_status = 0;      // backend status of the last call that reached it
 
 public:
     explicit RayTracer() = default;
@@ -54,4 +55,7 @@ public:
     RayFrame &getPreviousFrame() { return getCurrentFrame(); }
     u32 getFrameCount() const { return m_frameCount; }
     rt_ctx *backend() const { return m_ctx; }
+    // 0, or the rt_status of the last backend call that failed (device out of memory, inconsistent
+    // scene streams ...).  The reference traps on a GL error; an embedding process gets a code here.
+    int status() const { return m_status; }
 };

@@ -13,9 +13,8 @@ void HipStorage::bindToUnit(i32 unit) const {
     m_slot = unit;
     if (!m_dirty || m_ctx == nullptr) return;
     const auto &w = m_mirror.words();
-    int rc = rt_upload(m_ctx, unit, w.data(), w.size() * sizeof(f32));
-    ASSERT(rc == RT_OK);
-    m_dirty = false;
+    m_status = rt_upload(m_ctx, unit, w.data(), w.size() * sizeof(f32));
+    if (m_status == RT_OK) m_dirty = false;   // a failed upload is tried again at the next bind
 }
 
 }  // namespace gpu

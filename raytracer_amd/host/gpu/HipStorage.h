@@ -15,11 +15,13 @@ class HipStorage : public Storage {
     HostStorage m_mirror;
     mutable i32 m_slot;
     mutable bool m_dirty = false;
+    mutable int m_status = 0;
 
 public:
     explicit HipStorage(rt_ctx *ctx, i32 slot = -1) : m_ctx(ctx), m_slot(slot) {}
     void upload(const Buffer &buffer) override;
     void bindToUnit(i32 unit) const override;
+    int status() const override { return m_status; }
     const std::vector<f32> &words() const { return m_mirror.words(); }
 };
 

@@ -9,6 +9,7 @@
 
 #include <cstring>
 #include <memory>
+#include <new>
 #include <string>
 
 namespace {
@@ -193,6 +194,18 @@ bool buildNamedScene(RayScene &scene, const std::string &name, const SceneParams
         }
         return true;
     }
+    if (name == "panel_floor") {
+        // One emissive rectangle (a model, so next-event estimation samples it) facing a large floor
+        // quad: the direct light a camera ray sees on the floor has a quadrature answer.  nu = 1..10: tenths
+        // of roughness (else the default material's 1.0); nv = 100..200: hundredths of metallic plus 100.
+        scene.addModel(procedural::LightPanel(glm::vec3{-0.3f, 1.5f, 0.8f}, glm::vec3{0.6f, 0, 0}, glm::vec3{0, 0, 0.4f}, glm::vec3(1.0f, 0.8f, 0.6f), 5.0f));
+        Material floor;
+        floor.albedo = glm::vec3(0.8f, 0.7f, 0.6f);
+        if (p.nu > 0 && p.nu <= 10) floor.roughness = static_cast<float>(p.nu) / 10.0f;
+        if (p.nv >= 100 && p.nv <= 200) floor.metallic = static_cast<float>(p.nv - 100) / 100.0f;
+        scene.addObject(Quad{glm::vec3{-5.0f, 0.0f, -5.0f}, glm::vec3{10.0f, 0, 0}, glm::vec3{0, 0, 10.0f}}, floor);
+        return true;
+    }
     if (name == "ties") {
         // A lit room whose floor is covered by nv coplanar copies of an nu x nu grid of squares:
         // every hit on it is a distance tie between triangles of one model.
@@ -222,6 +235,27 @@ bool buildNamedScene(RayScene &scene, const std::string &name, const SceneParams
     return false;
 }
 
+// No exception leaves the C boundary: allocation failures become RT_ERR_NOMEM (or a null handle),
+// anything else RT_ERR_INVALID.
+template <typename Body>
+int guarded(Body body) {
+    try {
+        return body();
+    } catch (const std::bad_alloc &) {
+        return RT_ERR_NOMEM;
+    } catch (...) {
+        return RT_ERR_INVALID;
+    }
+}
+template <typename T, typename Body>
+T *guardedHandle(Body body) {
+    try {
+        return body();
+    } catch (...) {
+        return nullptr;
+    }
+}
+
 }  // namespace
 
 struct rth_scene {
@@ -237,13 +271,15 @@ extern "C" {
 
 rth_scene *rth_scene_build(const char *name, const int32_t *iparams, int n) {
     if (name == nullptr) return nullptr;
-    auto holder = std::make_unique<rth_scene>();
-    holder->scene.initialize(nullptr);
-    const SceneParams params = parseParams(iparams, n);
-    BvhModeScope scope(params.bvh);
-    if (!buildNamedScene(holder->scene, name, params)) return nullptr;
-    holder->scene.submit();
-    return holder.release();
+    return guardedHandle<rth_scene>([&]() -> rth_scene * {
+        auto holder = std::make_unique<rth_scene>();
+        holder->scene.initialize(nullptr);
+        const SceneParams params = parseParams(iparams, n);
+        BvhModeScope scope(params.bvh);
+        if (!buildNamedScene(holder->scene, name, params)) return nullptr;
+        holder->scene.submit();
+        return holder.release();
+    });
 }
 
 void rth_scene_free(rth_scene *scene) { delete scene; }
@@ -274,7 +310,9 @@ int rth_scene_stream(const rth_scene *s, int slot, const float **words, size_t *
 int rth_scene_model_stats(const rth_scene *s, int model, int32_t out[10]) {
     if (s == nullptr || out == nullptr || model < 0 || model >= static_cast<int>(s->scene.models().size())) return RT_ERR_INVALID;
     const Model &m = *s->scene.models()[model];
-    const Model::TreeStats t = m.treeStats();
+    Model::TreeStats t;
+    const int rc = guarded([&]() -> int { t = m.treeStats(); return RT_OK; });
+    if (rc != RT_OK) return rc;
     out[0] = static_cast<int32_t>(m.bvh.getNodes().size());
     out[1] = static_cast<int32_t>(m.meshData.identifiers.size());
     out[2] = static_cast<int32_t>(m.meshData.vertices.size());
@@ -320,42 +358,50 @@ int rth_camera_make(rt_camera *out, const float position[3], float yaw, float pi
 
 rth_engine *rth_engine_create(const char *scene_name, const int32_t *iparams, int n, const float position[3], float yaw, float pitch,
                               float fov, int w, int h, int bounces, int rpp, int type, int device) {
-    if (scene_name == nullptr || position == nullptr) return nullptr;
-    auto holder = std::make_unique<rth_engine>();
-    const RayCamera cam = makeCamera(position, yaw, pitch, fov, w, h, bounces, rpp);
-    if (!holder->engine.initialize(cam, type == RT_TYPE_SPECTRAL ? RayTracer::Type::Spectral : RayTracer::Type::RGB, device)) return nullptr;
-    const SceneParams params = parseParams(iparams, n);
-    BvhModeScope scope(params.bvh);
-    if (!buildNamedScene(holder->engine.getScene(), scene_name, params)) return nullptr;
-    holder->engine.getScene().submit();
-    return holder.release();
+    if (scene_name == nullptr || position == nullptr || w <= 0 || h <= 0) return nullptr;
+    return guardedHandle<rth_engine>([&]() -> rth_engine * {
+        auto holder = std::make_unique<rth_engine>();
+        const RayCamera cam = makeCamera(position, yaw, pitch, fov, w, h, bounces, rpp);
+        if (!holder->engine.initialize(cam, type == RT_TYPE_SPECTRAL ? RayTracer::Type::Spectral : RayTracer::Type::RGB, device)) return nullptr;
+        const SceneParams params = parseParams(iparams, n);
+        BvhModeScope scope(params.bvh);
+        if (!buildNamedScene(holder->engine.getScene(), scene_name, params)) return nullptr;
+        holder->engine.getScene().submit();
+        return holder.release();
+    });
 }
 
 int rth_engine_render(rth_engine *e, int frames) {
     if (e == nullptr || frames < 0) return RT_ERR_INVALID;
-    e->engine.render(static_cast<u32>(frames));
-    e->frames += frames;
-    return RT_OK;
+    return guarded([&]() -> int {
+        e->engine.render(static_cast<u32>(frames));
+        const int rc = e->engine.getRayTracer().status();   // device out of memory, refused scene ...: handed on, not trapped
+        if (rc == RT_OK) e->frames += frames;
+        return rc;
+    });
 }
 
 int rth_engine_frame(rth_engine *e, float *rgba, size_t floats) {
     if (e == nullptr || rgba == nullptr) return RT_ERR_INVALID;
-    RayFrame &f = e->engine.getRayTracer().getCurrentFrame();
-    if (floats != f.rgba.size()) return RT_ERR_INVALID;
-    std::memcpy(rgba, f.rgba.data(), floats * sizeof(float));
-    return e->frames;
+    return guarded([&]() -> int {
+        RayFrame &f = e->engine.getRayTracer().getCurrentFrame();
+        if (e->engine.getRayTracer().status() != RT_OK) return e->engine.getRayTracer().status();
+        if (floats != f.rgba.size()) return RT_ERR_INVALID;
+        std::memcpy(rgba, f.rgba.data(), floats * sizeof(float));
+        return e->frames;
+    });
 }
 
 void rth_engine_free(rth_engine *e) { delete e; }
 
 int rth_write_png(const char *path, const uint8_t *rgba8, int width, int height) {
-    if (path == nullptr) return RT_ERR_INVALID;
-    return imageio::WritePNG(path, rgba8, width, height) ? RT_OK : RT_ERR_INVALID;
+    if (path == nullptr || rgba8 == nullptr) return RT_ERR_INVALID;
+    return guarded([&]() -> int { return imageio::WritePNG(path, rgba8, width, height) ? RT_OK : RT_ERR_INVALID; });
 }
 
 int rth_write_pfm(const char *path, const float *rgba, int width, int height, float scale) {
-    if (path == nullptr) return RT_ERR_INVALID;
-    return imageio::WritePFM(path, rgba, width, height, scale) ? RT_OK : RT_ERR_INVALID;
+    if (path == nullptr || rgba == nullptr) return RT_ERR_INVALID;
+    return guarded([&]() -> int { return imageio::WritePFM(path, rgba, width, height, scale) ? RT_OK : RT_ERR_INVALID; });
 }
 
 }  // extern "C"

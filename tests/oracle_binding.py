@@ -29,6 +29,8 @@ lib.orc_camera_ray.argtypes = [C.POINTER(RtCamera), C.c_int, C.c_int, C.c_uint32
 lib.orc_hit.argtypes = [_vp, _fp, _fp, _fp]
 lib.orc_display.argtypes = [_vp, C.c_size_t, _vp]
 
+lib.orc_eval_colour.argtypes = [C.c_int, _vp, C.c_size_t, _vp]
+
 THREADS = min(8, os.cpu_count() or 1)
 
 
@@ -37,6 +39,18 @@ def display(rgba_mean):
     a = np.ascontiguousarray(rgba_mean, dtype=np.float32)
     out = np.empty(a.shape[:-1] + (4,), np.uint8)
     lib.orc_display(a.ctypes.data_as(_vp), a.size // 4, out.ctypes.data_as(_vp))
+    return out
+
+
+def eval_colour(fn, values=None, items=1):
+    """The checker's colour functions/tables on rows of inputs (same numbering as rt_eval_colour)."""
+    width_out = (3, 1, 1, 3, 193)[fn]
+    a = None
+    if values is not None:
+        a = np.ascontiguousarray(values, dtype=np.float32)
+        items = a.shape[0] if a.ndim > 1 else a.size
+    out = np.empty((items, width_out), np.float32)
+    assert lib.orc_eval_colour(fn, a.ctypes.data_as(_vp) if a is not None else None, items, out.ctypes.data_as(_vp)) == 0
     return out
 
 

@@ -284,3 +284,107 @@ def test_progressive_jpeg_is_refused_with_an_empty_texture(tmp_path):
     b.node(mesh=b.mesh([b.primitive(p, i, m, normals=n, uvs=uv)]), root=True)
     tex = load(b.write(tmp_path / "prog.glb")).streams[5]
     assert tex.size == 5 and list(i32(tex[:3])) == [0, 0, 0]      # header only, no texels
+
+
+# ---- hostile files: the loader is the trust boundary for external data --------------------------
+def _two_triangles():
+    pos = np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0]], np.float32)
+    return pos, [0, 1, 2, 0, 2, 3]
+
+
+def _load_or_none(path):
+    try:
+        return load(path)
+    except capi.RtError:
+        return None
+
+
+def test_position_accessor_must_be_packed_float3(tmp_path):
+    """POSITION and NORMAL are read as tightly packed float3.  An accessor declared SCALAR, VEC2 or
+    byte-typed passes a per-element bounds check but would be over-read by up to 3x: such a primitive
+    contributes nothing (and nothing is read past the binary chunk)."""
+    pos, idx = _two_triangles()
+    for kind, component in (("SCALAR", FLOAT), ("VEC2", FLOAT), ("VEC3", U8), ("VEC4", FLOAT)):
+        g = GlbBuilder()
+        prim = g.primitive(pos, idx)
+        acc = g.doc["accessors"][prim["attributes"]["POSITION"]]
+        acc["type"], acc["componentType"] = kind, component
+        acc["count"] = len(g.bin)            # as many one-byte elements as the buffer holds
+        g.node(mesh=g.mesh([prim]), root=True)
+        sc = _load_or_none(g.write(tmp_path / f"pos_{kind}_{component}.glb"))
+        assert sc is None or sc.model_stats(0)["triangles"] == 0
+
+
+def test_normal_accessor_of_the_wrong_shape_is_ignored(tmp_path):
+    pos, idx = _two_triangles()
+    g = GlbBuilder()
+    prim = g.primitive(pos, idx, normals=np.tile([0, 0, 1.0], (4, 1)))
+    g.doc["accessors"][prim["attributes"]["NORMAL"]]["type"] = "SCALAR"     # 4 floats declared, 12 would be read
+    g.node(mesh=g.mesh([prim]), root=True)
+    sc = load(g.write(tmp_path / "nrm.glb"))
+    d, verts = model_verts(sc)
+    assert sc.model_stats(0)["triangles"] == 2
+    assert np.allclose(verts[:, 3:6], [0, 1, 0])                             # the loader's default normal
+
+
+@pytest.mark.parametrize("index_type", [U8, U16, U32])
+def test_indices_beyond_the_vertex_count_drop_their_triangle(tmp_path, index_type):
+    pos, _ = _two_triangles()
+    big = {U8: 200, U16: 60000, U32: 0xFFFFFFF0}[index_type]
+    g = GlbBuilder()
+    g.node(mesh=g.mesh([g.primitive(pos, [0, 1, 2, 0, 2, big, 4, 1, 2, 0, 2, 3], index_type=index_type)]), root=True)
+    sc = load(g.write(tmp_path / "idx.glb"))
+    d, verts = model_verts(sc)
+    assert sc.model_stats(0)["triangles"] == 2                               # the two triangles with valid corners
+    assert d["ident"][:, :3].max() < 4
+
+
+def test_index_accessor_of_the_wrong_shape_or_type_is_refused(tmp_path):
+    pos, idx = _two_triangles()
+    for kind, component in (("VEC3", U16), ("SCALAR", FLOAT)):
+        g = GlbBuilder()
+        prim = g.primitive(pos, idx)
+        acc = g.doc["accessors"][prim["indices"]]
+        acc["type"], acc["componentType"] = kind, component
+        g.node(mesh=g.mesh([prim]), root=True)
+        sc = _load_or_none(g.write(tmp_path / f"idx_{kind}.glb"))
+        assert sc is None or sc.model_stats(0)["triangles"] == 0
+
+
+@pytest.mark.parametrize("field,value", [("count", 1e30), ("count", -5), ("byteOffset", 1e18), ("byteOffset", -4)])
+def test_accessor_fields_out_of_range_are_refused(tmp_path, field, value):
+    pos, idx = _two_triangles()
+    g = GlbBuilder()
+    prim = g.primitive(pos, idx)
+    g.doc["accessors"][prim["attributes"]["POSITION"]][field] = value
+    g.node(mesh=g.mesh([prim]), root=True)
+    sc = _load_or_none(g.write(tmp_path / "range.glb"))
+    assert sc is None or sc.model_stats(0)["triangles"] == 0
+
+
+def test_strided_view_whose_packed_extent_leaves_the_buffer_is_refused(tmp_path):
+    """byteStride 4 makes every 12-byte element start inside the chunk while `count` packed float3
+    would not fit: the packed read must not happen."""
+    pos, idx = _two_triangles()
+    g = GlbBuilder()
+    prim = g.primitive(pos, idx)
+    acc = g.doc["accessors"][prim["attributes"]["POSITION"]]
+    g.doc["bufferViews"][acc["bufferView"]]["byteStride"] = 4
+    acc["count"] = (len(g.bin) - 12) // 4 + 1
+    g.node(mesh=g.mesh([prim]), root=True)
+    sc = _load_or_none(g.write(tmp_path / "stride.glb"))
+    assert sc is None or sc.model_stats(0)["triangles"] == 0
+
+
+def test_jpeg_header_claiming_a_huge_image_leaves_the_texture_empty(tmp_path):
+    import struct
+    sof = b"\xff\xc0" + struct.pack(">HBHHB", 17, 8, 65535, 65535, 3) + bytes([1, 0x11, 0, 2, 0x11, 0, 3, 0x11, 0])
+    fake = b"\xff\xd8" + sof + b"\xff\xd9"
+    pos, idx = _two_triangles()
+    g = GlbBuilder()
+    tex = g.texture(fake)
+    mat = g.material(pbrMetallicRoughness={"baseColorTexture": {"index": tex}})
+    g.node(mesh=g.mesh([g.primitive(pos, idx, material=mat, uvs=pos[:, :2])]), root=True)
+    sc = load(g.write(tmp_path / "huge.glb"))
+    assert sc.model_stats(0)["triangles"] == 2
+    assert sc.streams[5].size < 64                                           # header words at most, no texels

@@ -171,6 +171,23 @@ def test_inconsistent_streams_are_refused_and_leave_no_scene(backend):
     upload(bad)
     assert hip.rt_commit_scene(ctx, scene.object_count, scene.models_count, scene.light_sources_count) == -5
 
+    # counts whose section offsets wrap in 32-bit arithmetic (858993460 * 5 = 4 (mod 2^32)) must not
+    # pass as small offsets
+    for column in (0, 1, 2):
+        bad = {s: v.copy() for s, v in good.items()}
+        bad[3].view(np.int32).reshape(-1, 4)[1][column] = 858993460 if column != 2 else 477218589   # * 9 wraps too
+        upload(bad)
+        assert hip.rt_commit_scene(ctx, scene.object_count, scene.models_count, scene.light_sources_count) == -5
+
+    # two parents sharing one child: a graph, which would be walked as an exponentially large tree
+    bad = {s: v.copy() for s, v in good.items()}
+    words = bad[4].view(np.int32)
+    root_left, root_right = int(words[node0 + 6]), int(words[node0 + 7])
+    assert bad[4][node0 + root_left * 9 + 8] == 0.0                    # the root's left child is an inner node
+    words[node0 + root_left * 9 + 7] = root_right                      # ... which now also claims the root's right child
+    upload(bad)
+    assert hip.rt_commit_scene(ctx, scene.object_count, scene.models_count, scene.light_sources_count) == -5
+
     upload(good)
     assert hip.rt_commit_scene(ctx, scene.object_count, scene.models_count, scene.light_sources_count) == 0
 
@@ -182,3 +199,20 @@ def test_random_soups_with_random_materials(backend, rtype, seed):
     at random including the corner values, random textures and analytic primitives."""
     nu = 40 if seed % 4 == 0 else 400          # shallow and deeper trees
     _, img, _ = both(backend, "fuzz", dict(nu=nu, nv=10, seed=seed), dict(width=56, height=40, bounces=6, ray_per_pixel=4), rtype)
+
+
+def test_host_layer_hands_backend_errors_on_instead_of_trapping():
+    """A camera the backend refuses (more bounces than it keeps stages for) through the C++ host
+    layer: RayEngine::render records the status, rth_engine_render returns it, the process lives."""
+    import ctypes as C
+    pos = (C.c_float * 3)(0.0, 1.0, -2.2)
+    eng = capi.host.rth_engine_create(b"cornell_quads", None, 0, pos, 90.0, 0.0, 50.0, 32, 24, 100, 1, capi.RT_TYPE_RGB, 0)
+    assert eng
+    try:
+        assert capi.host.rth_engine_render(eng, 1) == -1          # RT_ERR_INVALID from rt_set_frame
+        out = np.empty((24, 32, 4), np.float32)
+        assert capi.host.rth_engine_frame(eng, out.ctypes.data_as(C.c_void_p), out.size) == 0   # nothing was rendered
+        assert not out.any()
+    finally:
+        capi.host.rth_engine_free(eng)
+    assert not capi.host.rth_engine_create(b"cornell_quads", None, 0, pos, 90.0, 0.0, 50.0, 0, 24, 3, 1, capi.RT_TYPE_RGB, 0)

@@ -26,6 +26,7 @@ SCENES = [
     ("textured_room", dict(nu=64, nv=16, tex_size=32)),
     ("mixed", dict(nu=96, nv=16)),
     ("interior", dict(nu=48, nv=12, tex_size=32)),
+    ("panel_floor", dict(nu=5, nv=160)),
 ]
 
 

@@ -76,3 +76,19 @@ def test_two_rank_reduce_equals_single_rank(tmp_path):
     want, _ = OracleScene(scene).render(cam, 0, 1, 2 * total, 1, threads=2)
     assert np.array_equal(got[..., 3], want[..., 3])                 # every frame counted once
     assert np.allclose(got[..., :3], want[..., :3], rtol=1e-6, atol=1e-7)   # only the addition order differs
+
+
+def test_bench_starts_its_own_ranks_and_reports_their_failure():
+    """`bench.py --gpus 2` without a launcher spawns two ranks itself; here, without a GPU, both must
+    refuse to run (no CPU fallback) and the parent must hand the failure on."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    if torch.cuda.is_available():
+        return   # covered by the GPU test of the same entry point
+    run = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert run.returncode != 0
+    assert run.stderr.count("bench.py needs a GPU") == 2
+    assert not [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
