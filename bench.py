@@ -231,7 +231,23 @@ def main():
         trace_s = st["trace_ms"] / 1e3
         launches = max(st["trace_launches"], 1)
         achieved = st["rays"] * b_ray / max(trace_s, 1e-12) / 1e9
-        traffic, traffic_note = measured_traffic(args)
+        lim = measured_limits(args)
+        traffic = traffic_upper = None
+        traffic_note = "not measured for this workload"
+        if lim:
+            per = lim["fabric_bytes_per_launch"]
+            traffic, traffic_upper = per["fetch_as_counted"] + per["write"], per["fetch_doubled"] + per["write"]
+            traffic_note = ("bytes per launch across the L2 -> fabric boundary, rocprofv3 FETCH_SIZE + WRITE_SIZE, " + LIMITS_PROFILE + "; FETCH_SIZE calibrated on known bytes "
+                            "(tools/microbench/fetch_calib): exact for the kernel's 64-byte per-lane gathers, half for 16-byte-per-lane streams, so `traffic` counts it as is and `traffic_upper` doubles it")
+        # Lanes of the traversal kernel, from the counted pass: a wave runs one phase per step.
+        steps = max(cst["wave_steps"], 1)
+        lanes = {
+            "holding_a_ray": round(cst["active_lane_steps"] / (64.0 * steps), 4),
+            "working": round((cst["node_visits"] + cst["leaf_visits"]) / (64.0 * steps), 4),
+            "inner_phase_share_of_steps": round(cst["inner_phase_steps"] / steps, 4),
+            "wave_steps_per_ray": round(steps / max(cst["rays"], 1), 4),
+            "rays_per_refill": round(cst["rays"] / max(cst["refills"], 1), 2),
+        }
         out = {
             "metric": "Mrays/s",
             "value": round(mrays, 3),
@@ -263,8 +279,20 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": traffic,
+                "traffic_upper": traffic_upper,
                 "traffic_frac": (round(traffic / (st["trace_ms"] / launches * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if traffic else None),
                 "traffic_note": traffic_note,
+                # `frac` prices the kernel's algorithmic bytes against HBM although the caches serve most of
+                # them (it can exceed 1).  The limit that binds is the one below with the largest fraction.
+                "binding": (lim["binding"] if lim else None),
+                "binding_frac": (lim["limits"][lim["binding"]].get("frac", lim["limits"][lim["binding"]].get("frac_high")) if lim else None),
+                "limits": ({k: {kk: vv for kk, vv in v.items() if kk != "what"} for k, v in lim["limits"].items()} if lim else None),
+                "limits_note": ("share of each machine limit the traversal kernel uses: VALU issue cycles, vector-L1 request rate, L2 read bandwidth, Infinity-Cache gather rate, HBM; "
+                                "rocprofv3 counters over microbenchmark or guide peaks, " + LIMITS_PROFILE.replace(".json", ".txt")) if lim else None,
+                "lanes": lanes,
+                "lane_use_pmc": (lim["lane_use"] if lim else None),
+                "l1_hit": (lim["l1_hit"] if lim else None),
+                "l2_hit": (lim["l2_hit"] if lim else None),
                 "bytes_per_ray": round(b_ray, 1),
                 "nodes_per_ray": round(nodes_per_ray, 3),
                 "tris_per_ray": round(tris_per_ray, 3),
@@ -303,6 +331,8 @@ def main():
             be.set_option(capi.RT_OPT_WIDE_BVH, 3)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, scene, cam, rtype)
+            # The other CPU baseline, the reference's own shaders on Mesa llvmpipe, cannot be produced here.
+            out["llvmpipe"] = "unavailable (no OpenGL 3.3 context can be created on this machine: no X server, EGL or OSMesa; running the reference's shader text was also refused in the build environment)"
         print(json.dumps(out), flush=True)
 
     be.close()
@@ -310,22 +340,20 @@ def main():
         dist.destroy_process_group()
 
 
-def measured_traffic(args):
-    """HBM-side bytes per k_trace launch from the committed PMC passes (profiles/r01_k_hbm_traffic.json).
-    Counters cannot be read from inside this process, so the figure is the one measured with rocprofv3
-    on this same command; it is only reported for the default workload it was measured on."""
-    path = os.path.join(ROOT, "profiles", "r01_k_hbm_traffic.json")
+LIMITS_PROFILE = "profiles/r02_c_limits.json"
+
+
+def measured_limits(args):
+    """What rocprofv3's counters say about the traversal kernel of this same command (tools/roofline_limits.sh
+    + tools/roofline_report.py -> profiles/r02_c_limits.json).  Counters cannot be read from inside this
+    process, so the figures are the ones measured on this command; they are only reported for the default
+    workload they were measured on."""
+    path = os.path.join(ROOT, LIMITS_PROFILE)
     default = (args.scene == "cornell_knot" and args.bvh == "reference" and args.wide is None and "RT_WIDE_BVH" not in os.environ and not args.spectral and (args.width, args.height, args.spp, args.bounces, args.nu, args.nv) == (1920, 1080, 64, 4, 2048, 213))
     if not default or not os.path.exists(path):
-        return None, "not measured for this workload"
+        return None
     with open(path) as f:
-        data = json.load(f)
-    for name, k in data["kernels"].items():
-        # the timed step's variant: no visit counting (first template argument), four-wide trees
-        # (sixth), not the second walk of tied rays (seventh)
-        if name.startswith("k_trace<false") and name.endswith("true, false>"):
-            return k["fetch_bytes"] + k["write_bytes"], "bytes per launch, rocprofv3 FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE, profiles/r01_k_hbm_traffic.json"
-    return None, "k_trace not found in profiles/r01_k_hbm_traffic.json"
+        return json.load(f)
 
 
 def cpu_baseline(args, scene, cam, rtype):

@@ -67,6 +67,14 @@ typedef struct rt_stats {
     uint64_t trace_launches;
     uint64_t max_stack;     /* most traversal-stack entries any ray held (only if counters enabled) */
     uint64_t retraced;      /* RT_OPT_WIDE_BVH 3: rays traced a second time, in the reference's order, after a distance tie */
+    /* Occupancy of the traversal kernel's lanes (only if counters enabled).  A wave of 64 lanes runs
+     * one phase per step, inner nodes or leaves; a lane does work in a step if it opens a node or a
+     * leaf in it: lane utilisation = (node_visits + leaf_visits) / (64 * wave_steps). */
+    uint64_t wave_steps;        /* loop steps of all waves that ran a phase */
+    uint64_t active_lane_steps; /* lanes holding a ray, summed over those steps */
+    uint64_t leaf_visits;       /* leaves opened */
+    uint64_t inner_phase_steps; /* steps that ran the inner-node phase */
+    uint64_t refills;           /* times a wave fetched new rays for its idle lanes */
 } rt_stats;
 
 /* Creates a context on HIP device `device`.  Replaces the GL context +

@@ -60,6 +60,11 @@ class RtStats(C.Structure):
         ("trace_launches", C.c_uint64),
         ("max_stack", C.c_uint64),
         ("retraced", C.c_uint64),
+        ("wave_steps", C.c_uint64),
+        ("active_lane_steps", C.c_uint64),
+        ("leaf_visits", C.c_uint64),
+        ("inner_phase_steps", C.c_uint64),
+        ("refills", C.c_uint64),
     ]
 
 

@@ -916,8 +916,8 @@ int allocPathBuffers(rt_ctx *ctx, uint64_t want64) {
         if ((rc = devAlloc(ctx, &ctx->pb.stages, (size_t)kMaxBounces + 2)) != RT_OK) return rc;
     }
     if (ctx->pb.counters == nullptr) {
-        if ((rc = devAlloc(ctx, &ctx->pb.counters, 8)) != RT_OK) return rc;
-        RT_HIP(hipMemsetAsync(ctx->pb.counters, 0, 8 * sizeof(unsigned long long), ctx->stream));
+        if ((rc = devAlloc(ctx, &ctx->pb.counters, kCounters)) != RT_OK) return rc;
+        RT_HIP(hipMemsetAsync(ctx->pb.counters, 0, kCounters * sizeof(unsigned long long), ctx->stream));
     }
     ctx->P = want;
     return RT_OK;
@@ -1623,7 +1623,7 @@ int rt_get_stats(rt_ctx *ctx, rt_stats *out) {
     if (ctx == nullptr || out == nullptr) return RT_ERR_INVALID;
     int rc = rt_sync(ctx);
     if (rc != RT_OK) return rc;
-    unsigned long long c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long c[kCounters] = {};
     if (ctx->pb.counters != nullptr) RT_HIP(hipMemcpy(c, ctx->pb.counters, sizeof c, hipMemcpyDeviceToHost));
     out->rays = c[0];
     out->camera_samples = ctx->cameraSamples;
@@ -1635,6 +1635,11 @@ int rt_get_stats(rt_ctx *ctx, rt_stats *out) {
     out->trace_launches = ctx->traceLaunches;
     out->max_stack = c[4];
     out->retraced = c[5];
+    out->wave_steps = c[6];
+    out->active_lane_steps = c[7];
+    out->leaf_visits = c[8];
+    out->inner_phase_steps = c[9];
+    out->refills = c[10];
     return RT_OK;
 }
 
@@ -1642,7 +1647,7 @@ int rt_reset_stats(rt_ctx *ctx) {
     if (ctx == nullptr) return RT_ERR_INVALID;
     int rc = rt_sync(ctx);
     if (rc != RT_OK) return rc;
-    if (ctx->pb.counters != nullptr) RT_HIP(hipMemset(ctx->pb.counters, 0, 8 * sizeof(unsigned long long)));
+    if (ctx->pb.counters != nullptr) RT_HIP(hipMemset(ctx->pb.counters, 0, kCounters * sizeof(unsigned long long)));
     ctx->traceMs = ctx->totalMs = 0.0;
     ctx->traceLaunches = 0;
     ctx->cameraSamples = 0;

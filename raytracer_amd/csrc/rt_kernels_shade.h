@@ -59,11 +59,13 @@ __global__ __launch_bounds__(kBlock) void k_connect(SceneView sc, Batch bt, Path
     for (uint32_t i = (blockIdx.x / kSubQueues) * kBlock + threadIdx.x; i < n; i += stride) {
         const uint32_t slot = qIn[i];
         const uint32_t path = slot - bt.P;
-        const RayRec sr = pb.rays[slot];
         const HitRec h = pb.hits[slot];
-        const float4 a = pb.neeA[path], b = pb.neeB[path], c = pb.neeC[path];
-        // RGB: a hit nearer than distToLight - 1e-4 contributes nothing; skip its material.
+        const float4 c = pb.neeC[path];
+        // RGB: a hit nearer than distToLight - 1e-4 contributes nothing; skip its material and the
+        // rest of its records (the test needs 32 of the 132 bytes a connection reads).
         if (!SPECTRAL && skipOccluded && !(h.t >= c.z - 1e-4f)) continue;
+        const RayRec sr = pb.rays[slot];
+        const float4 a = pb.neeA[path], b = pb.neeB[path];
         const ShadowHit s = shadowHitOf(sc, sr, h, pb.counters);
         if (h.id != kMiss) shaded++;
         const V3 sd = v3(sr.dx, sr.dy, sr.dz);

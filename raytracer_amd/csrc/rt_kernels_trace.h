@@ -259,6 +259,9 @@ __global__ __launch_bounds__(kBlock, WIDE ? (ALPHA ? RT_WWIDE_ALPHA : RT_WWIDE)
     bool drained = false;    // every source has been seen empty
 
     uint32_t cntNodes = 0, cntTris = 0, maxSp = 0;
+    // COUNT only, wave-uniform: loop steps that ran a phase, the active lanes summed over those steps,
+    // steps that ran the inner-node phase, refills; per lane: leaves opened.
+    uint32_t cntSteps = 0, cntActive = 0, cntInnerSteps = 0, cntRefills = 0, cntLeaves = 0;
     bool active = false;
     LaneRay r;
     r.slot = 0;
@@ -386,6 +389,7 @@ __global__ __launch_bounds__(kBlock, WIDE ? (ALPHA ? RT_WWIDE_ALPHA : RT_WWIDE)
                 }
             } else {
                 const uint32_t mine = base + (uint32_t)__popcll(idleMask & ((1ull << lane) - 1ull));
+                if (COUNT) cntRefills++;
                 if (!active && mine < n) {
                     const uint32_t *q = (src < kSubQueues) ? qExt + (size_t)src * pb.subCap
                                                              : pb.qShadow + (size_t)(src - kSubQueues) * pb.subCap;
@@ -461,6 +465,11 @@ __global__ __launch_bounds__(kBlock, WIDE ? (ALPHA ? RT_WWIDE_ALPHA : RT_WWIDE)
             nActive -= nPending;
         }
         const bool innerPhase = nInner * 64 >= nActive * innerShare;
+        if (COUNT) {
+            cntSteps++;
+            cntActive += (uint32_t)nActive;
+            cntInnerSteps += innerPhase ? 1u : 0u;
+        }
         bool pop = false, occluded = false;
         if (innerPhase) {
             if (WIDE) {
@@ -496,6 +505,7 @@ __global__ __launch_bounds__(kBlock, WIDE ? (ALPHA ? RT_WWIDE_ALPHA : RT_WWIDE)
             const uint32_t code = ~(uint32_t)r.ref;
             const uint32_t first = code >> 2, ntri = code & 3u;
             bool parked = false;
+            if (COUNT) cntLeaves++;
             if (WIDE && !ALPHA) {
                 // The usual leaf holds one or two triangles: fetch both in one round trip (the binary
                 // variants have no registers to spare for this: -10 % there, +2 % here).
@@ -586,12 +596,18 @@ __global__ __launch_bounds__(kBlock, WIDE ? (ALPHA ? RT_WWIDE_ALPHA : RT_WWIDE)
         for (int off = 32; off > 0; off >>= 1) {
             cntNodes += __shfl_down(cntNodes, off);
             cntTris += __shfl_down(cntTris, off);
+            cntLeaves += __shfl_down(cntLeaves, off);
             maxSp = max(maxSp, (uint32_t)__shfl_down(maxSp, off));
         }
         if (lane == 0) {
             atomicAdd(&pb.counters[1], (unsigned long long)cntNodes);
             atomicAdd(&pb.counters[2], (unsigned long long)cntTris);
             atomicMax(&pb.counters[4], (unsigned long long)maxSp);
+            atomicAdd(&pb.counters[6], (unsigned long long)cntSteps);
+            atomicAdd(&pb.counters[7], (unsigned long long)cntActive);
+            atomicAdd(&pb.counters[8], (unsigned long long)cntLeaves);
+            atomicAdd(&pb.counters[9], (unsigned long long)cntInnerSteps);
+            atomicAdd(&pb.counters[10], (unsigned long long)cntRefills);
         }
     }
 }

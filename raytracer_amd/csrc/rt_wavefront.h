@@ -31,6 +31,7 @@ constexpr int kStackDepth = 32;      // int stack[32], src/RayScene.cpp:682
 #endif
 constexpr int kWideStack = RT_WSTACK;   // LDS stack entries of the four-wide variants; deeper entries go to memory
 constexpr int kBlock = 256;
+constexpr int kCounters = 16;
 constexpr int kMaxBounces = 62;      // stages kept on the device
 // Default ceiling of paths in flight per batch (~190 B of device memory each).  Every kernel of
 // a batch ends with a drain tail in which most of the chip idles, so few large batches beat many
@@ -106,7 +107,8 @@ struct PathBuffers {
     uint32_t *qShadow;   // [kSubQueues * subCap]
     uint32_t subCap;     // capacity of one sub-queue
     Stage *stages;       // [kMaxBounces + 2]: one per bounce and the last shadow stage
-    unsigned long long *counters;  // [8]: 0 rays, 1 nodeVisits, 2 triTests, 3 shadedHits, 4 deepest traversal stack
+    unsigned long long *counters;  // [kCounters]: 0 rays, 1 nodeVisits, 2 triTests, 3 shadedHits, 4 deepest traversal stack, 5 rays traced again,
+                                   // 6 wave steps of k_trace, 7 active lanes summed over them, 8 leaves opened, 9 steps in the inner-node phase, 10 refills
     // Four-wide traversal only: stack entries beyond the LDS part, [wave][overflowDepth][64].
     int32_t *overflow;
     uint32_t overflowDepth;
