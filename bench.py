@@ -173,8 +173,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    be.reserve(args.spp)   # path buffers for one step: no allocation inside any render call below
     # Per-ray visit counts of this workload for the algorithmic byte model: one whole step with the
-    # counters on (untimed; it also sizes the path buffers, so no allocation lands in the timed region).
+    # counters on (untimed).
     be.set_counters(True)
     be.reset_stats()
     be.render(first_frame=1, n_frames=args.spp, stride=1)

@@ -108,6 +108,14 @@ int rt_set_frame(rt_ctx *ctx, const rt_camera *cam, const float sky_linear[3], i
  * Adds each frame's colour into the sum buffer.  Asynchronous on the context's stream. */
 int rt_render(rt_ctx *ctx, uint32_t first_frame, uint32_t n_frames, uint32_t frame_stride);
 
+/* Allocates now the per-path device memory that rt_render(first, n_frames, stride) would need
+ * (no reference counterpart: the reference's per-fragment state lives in shader registers).  rt_render
+ * grows the buffers on demand, which puts a hipMalloc into the first call of a new size; a caller
+ * that wants its render calls free of allocation, or wants an out-of-memory answer before it starts,
+ * calls this after rt_set_frame.  Same ceiling as rt_render (RT_OPT_MAX_PATHS, half of the free device
+ * memory): a request above it is served in several batches, as it would be by rt_render. */
+int rt_reserve(rt_ctx *ctx, uint32_t n_frames);
+
 /* RayTracer::reset (src/RayTracer.cpp:1467-1470): zero the sum buffer and frame count. */
 int rt_reset_accum(rt_ctx *ctx);
 

@@ -22,7 +22,7 @@ RT_OPT_STRATIFIED = 10
 
 # Every symbol include/rt_hip.h declares.
 HIP_SYMBOLS = [
-    "rt_create", "rt_destroy", "rt_upload", "rt_commit_scene", "rt_resize", "rt_set_frame", "rt_render",
+    "rt_create", "rt_destroy", "rt_upload", "rt_commit_scene", "rt_resize", "rt_set_frame", "rt_render", "rt_reserve",
     "rt_reset_accum", "rt_sync", "rt_readback", "rt_display_rgba8", "rt_display_rgba8_noalloc", "rt_restore_accum", "rt_accum_device_ptr", "rt_bind_accum", "rt_add_frames",
     "rt_trace_primary", "rt_eval_colour", "rt_get_stats", "rt_reset_stats", "rt_set_counters", "rt_set_option", "rt_set_tile_shard", "rt_strerror", "rt_last_hip_error",
     "rt_comm_unique_id", "rt_comm_init", "rt_reduce",
@@ -93,6 +93,7 @@ hip.rt_commit_scene.argtypes = [_vp, _i, _i, _i]
 hip.rt_resize.argtypes = [_vp, _i, _i]
 hip.rt_set_frame.argtypes = [_vp, C.POINTER(RtCamera), _fp, _i]
 hip.rt_render.argtypes = [_vp, _u32, _u32, _u32]
+hip.rt_reserve.argtypes = [_vp, _u32]
 hip.rt_reset_accum.argtypes = [_vp]
 hip.rt_sync.argtypes = [_vp]
 hip.rt_readback.argtypes = [_vp, _vp, _sz, C.POINTER(_u32)]
@@ -243,6 +244,10 @@ class Backend:
 
     def render(self, first_frame=1, n_frames=1, stride=1):
         self._check(hip.rt_render(self._ctx, first_frame, n_frames, stride))
+
+    def reserve(self, n_frames):
+        """Allocates the path buffers a render call of n_frames needs, ahead of the call."""
+        self._check(hip.rt_reserve(self._ctx, n_frames))
 
     def sync(self):
         self._check(hip.rt_sync(self._ctx))

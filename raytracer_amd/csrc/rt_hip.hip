@@ -1450,6 +1450,16 @@ int rt_render(rt_ctx *ctx, uint32_t first_frame, uint32_t n_frames, uint32_t fra
     return RT_OK;
 }
 
+int rt_reserve(rt_ctx *ctx, uint32_t n_frames) {
+    if (ctx == nullptr || n_frames == 0) return RT_ERR_INVALID;
+    if (!ctx->frameSet) return RT_ERR_STATE;
+    RT_HIP(hipSetDevice(ctx->device));
+    const uint64_t totalPlanes = (uint64_t)n_frames * ctx->fp.S;
+    if (totalPlanes > 0xffffffffull) return RT_ERR_INVALID;
+    RT_HIP(hipStreamSynchronize(ctx->stream));   // the buffers may be in use by queued work
+    return ensurePathBuffers(ctx, totalPlanes * ctx->fp.npt);
+}
+
 int rt_reset_accum(rt_ctx *ctx) {
     if (ctx == nullptr) return RT_ERR_INVALID;
     if (ctx->dAccum == nullptr) return RT_ERR_STATE;

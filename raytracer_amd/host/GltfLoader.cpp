@@ -2,8 +2,8 @@
 //
 // The reference delegates parsing to tinygltf and image decoding to stb_image
 // (reference src/MeshData.cpp:419-590); neither is available here, so this file
-// carries a small JSON reader, the GLB container parse and a PNG decoder (zlib)
-// and then builds the MeshData the way the reference does:
+// carries a small JSON reader and the GLB container parse (the image decoders are PngDecode.cpp
+// and JpegDecode.cpp) and then builds the MeshData the way the reference does:
 //   * node hierarchy walked depth first, world = parent * local, local from
 //     `matrix` or translate * rotate * scale (src/MeshData.cpp:11-45,169-197);
 //   * positions = world * (p,1); normals = normalize(transpose(inverse(mat3(world))) * n),
@@ -16,9 +16,8 @@
 //   * materials from pbrMetallicRoughness + the KHR volume/emissive_strength/transmission/ior
 //     extensions (src/MeshData.cpp:199-323);
 //   * textures: 8-bit images become k/255.0f texels (src/MeshData.cpp:475-528).  Images are
-//     decoded to RGBA like tinygltf's default loader does; PNG (8-bit, non-interlaced, here) and
-//     baseline JPEG (JpegDecode.cpp) are decoded — other encodings leave the texture without
-//     data, with a message.
+//     decoded to RGBA like tinygltf's default loader does; PNG and Huffman-coded 8-bit JPEG are
+//     read — other encodings leave the texture without data, with a message.
 #include "MeshData.h"
 #include "ImageIO.h"
 
@@ -26,7 +25,6 @@
 #include "glm/gtc/quaternion.hpp"
 #include "glm/gtc/type_ptr.hpp"
 
-#include <zlib.h>
 
 #include <cstdio>
 #include <cstdlib>
@@ -161,90 +159,6 @@ public:
         return ok;
     }
 };
-
-// ---- PNG (8-bit, non-interlaced) -> RGBA8 ----------------------------------------------
-uint32_t be32(const unsigned char *p) { return (uint32_t(p[0]) << 24) | (uint32_t(p[1]) << 16) | (uint32_t(p[2]) << 8) | uint32_t(p[3]); }
-
-bool decodePngRGBA(const unsigned char *data, size_t size, int &width, int &height, std::vector<unsigned char> &rgba) {
-    static const unsigned char sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
-    if (size < 8 || std::memcmp(data, sig, 8) != 0) return false;
-    size_t at = 8;
-    int bitDepth = 0, colorType = 0, interlace = 0;
-    std::vector<unsigned char> idat, palette, trns;
-    while (at + 12 <= size) {
-        uint32_t len = be32(data + at);
-        const unsigned char *type = data + at + 4, *body = data + at + 8;
-        if (at + 12 + len > size) return false;
-        if (!std::memcmp(type, "IHDR", 4) && len >= 13) {
-            width = static_cast<int>(be32(body));
-            height = static_cast<int>(be32(body + 4));
-            bitDepth = body[8];
-            colorType = body[9];
-            interlace = body[12];
-        } else if (!std::memcmp(type, "PLTE", 4)) {
-            palette.assign(body, body + len);
-        } else if (!std::memcmp(type, "tRNS", 4)) {
-            trns.assign(body, body + len);
-        } else if (!std::memcmp(type, "IDAT", 4)) {
-            idat.insert(idat.end(), body, body + len);
-        } else if (!std::memcmp(type, "IEND", 4)) {
-            break;
-        }
-        at += 12 + len;
-    }
-    if (width <= 0 || height <= 0 || width > 16384 || height > 16384 || bitDepth != 8 || interlace != 0) return false;
-    int channels = colorType == 0 ? 1 : colorType == 2 ? 3 : colorType == 3 ? 1 : colorType == 4 ? 2 : colorType == 6 ? 4 : 0;
-    if (channels == 0) return false;
-    const size_t stride = static_cast<size_t>(width) * channels;
-    std::vector<unsigned char> raw((stride + 1) * height);
-    uLongf rawLen = static_cast<uLongf>(raw.size());
-    if (uncompress(raw.data(), &rawLen, idat.data(), static_cast<uLong>(idat.size())) != Z_OK || rawLen != raw.size()) return false;
-
-    std::vector<unsigned char> img(stride * height);
-    for (int y = 0; y < height; ++y) {
-        const unsigned char filter = raw[(stride + 1) * y];
-        const unsigned char *src = &raw[(stride + 1) * y + 1];
-        unsigned char *dst = &img[stride * y];
-        const unsigned char *up = y > 0 ? &img[stride * (y - 1)] : nullptr;
-        for (size_t i = 0; i < stride; ++i) {
-            int a = i >= static_cast<size_t>(channels) ? dst[i - channels] : 0;
-            int b = up ? up[i] : 0;
-            int c = (up && i >= static_cast<size_t>(channels)) ? up[i - channels] : 0;
-            int pred = 0;
-            switch (filter) {
-                case 1: pred = a; break;
-                case 2: pred = b; break;
-                case 3: pred = (a + b) / 2; break;
-                case 4: {
-                    int pa = std::abs(b - c), pb = std::abs(a - c), pc = std::abs(a + b - 2 * c);
-                    pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
-                    break;
-                }
-                default: break;
-            }
-            dst[i] = static_cast<unsigned char>(src[i] + pred);
-        }
-    }
-    rgba.resize(static_cast<size_t>(width) * height * 4);
-    for (size_t px = 0; px < static_cast<size_t>(width) * height; ++px) {
-        const unsigned char *s = &img[px * channels];
-        unsigned char *d = &rgba[px * 4];
-        switch (colorType) {
-            case 0: d[0] = d[1] = d[2] = s[0]; d[3] = 255; break;
-            case 2: d[0] = s[0]; d[1] = s[1]; d[2] = s[2]; d[3] = 255; break;
-            case 3: {
-                size_t k = s[0];
-                if (k * 3 + 2 >= palette.size() + 0 && k * 3 + 2 > palette.size() - 1 + 0) { d[0] = d[1] = d[2] = 0; }
-                else { d[0] = palette[k * 3]; d[1] = palette[k * 3 + 1]; d[2] = palette[k * 3 + 2]; }
-                d[3] = k < trns.size() ? trns[k] : 255;
-                break;
-            }
-            case 4: d[0] = d[1] = d[2] = s[0]; d[3] = s[1]; break;
-            default: d[0] = s[0]; d[1] = s[1]; d[2] = s[2]; d[3] = s[3]; break;
-        }
-    }
-    return true;
-}
 
 // ---- glTF document helpers ------------------------------------------------------------
 struct Glb {
@@ -527,9 +441,12 @@ void convertTexture(const Glb &glb, const Json &texture, MeshData::Texture &out)
             std::cout << "\tJPEG image not decoded (" << why << "); texture left empty" << std::endl;
             return;
         }
-    } else if (!decodePngRGBA(bytes, length, w, h, rgba)) {
-        std::cout << "\tImage encoding not supported (8-bit non-interlaced PNG and baseline JPEG are decoded); texture left empty" << std::endl;
-        return;
+    } else {
+        std::string why;
+        if (!imageio::DecodePngRGBA(bytes, length, w, h, rgba, why)) {
+            std::cout << "\tImage not decoded (" << why << "; PNG and JPEG are the encodings read); texture left empty" << std::endl;
+            return;
+        }
     }
     if (w <= 0 || h <= 0 || rgba.size() != static_cast<size_t>(w) * static_cast<size_t>(h) * 4) return;
     out.width = w;

@@ -19,8 +19,12 @@ bool WritePNG(const std::string &path, const uint8_t *rgba8, int width, int heig
 // channels scaled by `scale` (1/frames turns a sum buffer into the mean) as little-endian PFM.
 bool WritePFM(const std::string &path, const float *rgba, int width, int height, float scale);
 
-// Baseline (Huffman, 8-bit, greyscale or YCbCr) JPEG -> RGBA8, rows top-down.  On failure
-// `why` says what is unsupported or broken.
+// Huffman-coded 8-bit JPEG (baseline, extended-sequential or progressive; greyscale or YCbCr)
+// -> RGBA8, rows top-down.  On failure `why` says what is unsupported or broken.
 bool DecodeJpegRGBA(const unsigned char *data, size_t size, int &width, int &height, std::vector<unsigned char> &rgba, std::string &why);
+
+// PNG (any colour type and bit depth of the standard, plain or Adam7-interlaced, tRNS
+// transparency) -> RGBA8, rows top-down; 16-bit samples keep their high byte.
+bool DecodePngRGBA(const unsigned char *data, size_t size, int &width, int &height, std::vector<unsigned char> &rgba, std::string &why);
 
 }  // namespace imageio

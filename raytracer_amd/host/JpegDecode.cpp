@@ -1,9 +1,9 @@
-// Baseline / extended-sequential JPEG (Huffman, 8-bit, 1 or 3 components, chroma subsampled
-// by 1 or 2 in each direction, restart intervals) -> RGBA8.  The reference decodes textures
-// with stb_image through tinygltf (reference src/MeshData.cpp:419-425, 558-580), which is not
-// available; this decoder follows the same family of algorithms (integer IDCT of the IJG slow
-// kind, triangle-filter chroma upsampling, fixed-point YCbCr conversion).  Progressive,
-// arithmetic-coded, 12-bit and CMYK files are refused.
+// Huffman-coded 8-bit JPEG -> RGBA8: baseline, extended-sequential and progressive frames, 1 or 3
+// components, chroma subsampled by 1 or 2 in each direction, restart intervals, interleaved and
+// per-component scans.  The reference decodes textures with stb_image through tinygltf (reference
+// src/MeshData.cpp:419-425, 558-580), which is not available; this decoder follows the same family
+// of algorithms (integer IDCT of the IJG slow kind, triangle-filter chroma upsampling, fixed-point
+// YCbCr conversion).  Arithmetic-coded, lossless, 12-bit and CMYK files are refused.
 #include "ImageIO.h"
 
 #include <cstdint>
@@ -26,9 +26,11 @@ struct Huffman {
 
 struct Component {
     int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0;
-    int blocksW = 0, blocksH = 0;      // allocated size in blocks (whole MCUs)
+    int blocksW = 0, blocksH = 0;            // allocated size in blocks (whole MCUs)
+    int blocksAcross = 0, blocksDown = 0;    // blocks that hold image samples: the extent of a scan of this component alone
     int dcPred = 0;
-    std::vector<unsigned char> plane;  // blocksW*8 x blocksH*8 samples
+    std::vector<unsigned char> plane;        // blocksW*8 x blocksH*8 samples
+    std::vector<short> coef;                 // blocksW x blocksH x 64 coefficients, kept when the file has several scans
 };
 
 struct BitReader {
@@ -84,12 +86,17 @@ int decodeSymbol(BitReader &br, const Huffman &h) {
 
 int extend(int v, int n) { return (n && v < (1 << (n - 1))) ? v - (1 << n) + 1 : v; }
 
-inline unsigned char clamp255(int x) { return static_cast<unsigned char>(x < 0 ? 0 : (x > 255 ? 255 : x)); }
+// DC prediction of a component: running sum of differences.  A damaged file can run it past the
+// range of int; it wraps then (defined for unsigned) instead of overflowing.
+inline int addWrapped(int sum, int diff) { return static_cast<int>(static_cast<unsigned>(sum) + static_cast<unsigned>(diff)); }
 
-// Integer inverse DCT, 12-bit fixed-point constants, columns then rows.
+inline unsigned char clamp255(long long x) { return static_cast<unsigned char>(x < 0 ? 0 : (x > 255 ? 255 : x)); }
+
+// Integer inverse DCT, 12-bit fixed-point constants, columns then rows.  The sums are kept in 64
+// bits: the coefficients of a well-formed file stay far below 2^31 here, those of a damaged one need not.
 #define F2F(x) (static_cast<int>((x) * 4096 + 0.5))
 #define IDCT_1D(s0, s1, s2, s3, s4, s5, s6, s7)                     \
-    int t0, t1, t2, t3, p1, p2, p3, p4, p5, x0, x1, x2, x3;        \
+    long long t0, t1, t2, t3, p1, p2, p3, p4, p5, x0, x1, x2, x3;  \
     p2 = s2; p3 = s6;                                               \
     p1 = (p2 + p3) * F2F(0.5411961f);                               \
     t2 = p1 + p3 * F2F(-1.847759065f);                              \
@@ -122,10 +129,10 @@ void idctBlock(unsigned char *out, int stride, const short data[64]) {
         } else {
             IDCT_1D(d[0], d[8], d[16], d[24], d[32], d[40], d[48], d[56])
             x0 += 512; x1 += 512; x2 += 512; x3 += 512;
-            v[0] = (x0 + t3) >> 10; v[56] = (x0 - t3) >> 10;
-            v[8] = (x1 + t2) >> 10; v[48] = (x1 - t2) >> 10;
-            v[16] = (x2 + t1) >> 10; v[40] = (x2 - t1) >> 10;
-            v[24] = (x3 + t0) >> 10; v[32] = (x3 - t0) >> 10;
+            v[0] = static_cast<int>((x0 + t3) >> 10); v[56] = static_cast<int>((x0 - t3) >> 10);
+            v[8] = static_cast<int>((x1 + t2) >> 10); v[48] = static_cast<int>((x1 - t2) >> 10);
+            v[16] = static_cast<int>((x2 + t1) >> 10); v[40] = static_cast<int>((x2 - t1) >> 10);
+            v[24] = static_cast<int>((x3 + t0) >> 10); v[32] = static_cast<int>((x3 - t0) >> 10);
         }
     }
     for (int i = 0; i < 8; ++i) {
@@ -176,200 +183,416 @@ void upsampleRow(unsigned char *out, const unsigned char *nearRow, const unsigne
 
 }  // namespace
 
-bool DecodeJpegRGBA(const unsigned char *data, size_t size, int &width, int &height, std::vector<unsigned char> &rgba, std::string &why) {
-    if (size < 4 || data[0] != 0xFF || data[1] != 0xD8) { why = "not a JPEG stream"; return false; }
+namespace {
+
+// One scan's parameters: spectral band [ss, se], successive-approximation bit positions (ah = the
+// previous pass's position, 0 on a first pass; al = this pass's).
+struct Scan {
+    int ss = 0, se = 63, ah = 0, al = 0;
+    int eobRun = 0;
+};
+
+// A whole block of a sequential scan: DC difference, then run/size pairs up to the end-of-block code.
+bool decodeSequentialBlock(BitReader &br, const Huffman &dcTable, const Huffman &acTable, Component &c, short *block) {
+    const int t = decodeSymbol(br, dcTable);
+    if (t < 0 || t > 11) return false;
+    c.dcPred = addWrapped(c.dcPred, extend(br.get(t), t));
+    block[0] = static_cast<short>(c.dcPred);
+    for (int k = 1; k < 64;) {
+        const int rs = decodeSymbol(br, acTable);
+        if (rs < 0) return false;
+        const int run = rs >> 4, sz = rs & 15;
+        if (sz == 0) {
+            if (run != 15) break;   // end of block
+            k += 16;
+            continue;
+        }
+        k += run;
+        if (k > 63) return false;
+        block[kZigzag[k]] = static_cast<short>(extend(br.get(sz), sz));
+        ++k;
+    }
+    return true;
+}
+
+// Progressive DC: the first pass carries the difference shifted down by al, later passes one more bit each.
+bool decodeProgressiveDC(BitReader &br, const Huffman &dcTable, Component &c, const Scan &sc, short *block) {
+    if (sc.ah == 0) {
+        const int t = decodeSymbol(br, dcTable);
+        if (t < 0 || t > 11) return false;
+        c.dcPred = addWrapped(c.dcPred, extend(br.get(t), t));
+        block[0] = static_cast<short>(static_cast<unsigned>(c.dcPred) << sc.al);
+    } else if (br.get(1)) {
+        block[0] = static_cast<short>(block[0] + (1 << sc.al));
+    }
+    return true;
+}
+
+// Progressive AC, first pass over a band: like the sequential codes, plus end-of-band runs that
+// close this block's band and that of the following eobRun blocks.
+bool decodeProgressiveACFirst(BitReader &br, const Huffman &acTable, Scan &sc, short *block) {
+    if (sc.eobRun > 0) {
+        --sc.eobRun;
+        return true;
+    }
+    for (int k = sc.ss; k <= sc.se;) {
+        const int rs = decodeSymbol(br, acTable);
+        if (rs < 0) return false;
+        const int run = rs >> 4, sz = rs & 15;
+        if (sz == 0) {
+            if (run < 15) {
+                sc.eobRun = (1 << run) - 1;
+                if (run) sc.eobRun += br.get(run);
+                break;
+            }
+            k += 16;
+            continue;
+        }
+        k += run;
+        if (k > sc.se) return false;
+        block[kZigzag[k]] = static_cast<short>(extend(br.get(sz), sz) * (1 << sc.al));
+        ++k;
+    }
+    return true;
+}
+
+// One more bit for a coefficient that earlier passes already made non-zero.
+inline void refineCoefficient(BitReader &br, short &value, int bit) {
+    if (br.get(1) && (value & bit) == 0) value = static_cast<short>(value > 0 ? value + bit : value - bit);
+}
+
+// Progressive AC, refinement pass: each code places one new +-1 coefficient (at bit al) after a
+// run of still-zero ones; every already non-zero coefficient passed on the way takes a correction bit.
+bool decodeProgressiveACRefine(BitReader &br, const Huffman &acTable, Scan &sc, short *block) {
+    const int bit = 1 << sc.al;
+    int k = sc.ss;
+    if (sc.eobRun > 0) {
+        --sc.eobRun;
+        for (; k <= sc.se; ++k) {
+            short &value = block[kZigzag[k]];
+            if (value != 0) refineCoefficient(br, value, bit);
+        }
+        return true;
+    }
+    while (k <= sc.se) {
+        const int rs = decodeSymbol(br, acTable);
+        if (rs < 0) return false;
+        int run = rs >> 4;
+        const int sz = rs & 15;
+        int placed = 0;
+        if (sz == 0) {
+            if (run < 15) {   // end of band: the rest of this block only refines
+                sc.eobRun = (1 << run) - 1;
+                if (run) sc.eobRun += br.get(run);
+                run = 64;
+            }   // else: sixteen zeros, i.e. fifteen and a "new coefficient" of value zero
+        } else {
+            if (sz != 1) return false;
+            placed = br.get(1) ? bit : -bit;
+        }
+        while (k <= sc.se) {
+            short &value = block[kZigzag[k++]];
+            if (value != 0) {
+                refineCoefficient(br, value, bit);
+            } else {
+                if (run == 0) {
+                    if (placed) value = static_cast<short>(placed);
+                    break;
+                }
+                --run;
+            }
+        }
+    }
+    return true;
+}
+
+struct Decoder {
+    const unsigned char *data;
+    size_t size;
+    std::string &why;
     uint16_t quant[4][64] = {};
     Huffman dc[4], ac[4];
     std::vector<Component> comps;
-    int restartInterval = 0, hMax = 1, vMax = 1;
-    bool haveFrame = false;
-    size_t at = 2;
-    while (at + 4 <= size) {
-        if (data[at] != 0xFF) { why = "marker expected"; return false; }
-        while (at < size && data[at] == 0xFF) ++at;   // fill bytes
-        if (at >= size) break;
-        const int marker = data[at++];
-        if (marker == 0xD9) break;
-        if (marker == 0x01 || (marker >= 0xD0 && marker <= 0xD7)) continue;
-        if (at + 2 > size) break;
-        const size_t len = (static_cast<size_t>(data[at]) << 8) | data[at + 1];
-        if (len < 2 || at + len > size) { why = "truncated segment"; return false; }
-        const unsigned char *seg = data + at + 2;
-        const size_t segLen = len - 2;
-        if (marker == 0xDB) {                               // quantisation tables
-            size_t o = 0;
-            while (o < segLen) {
-                const int pq = seg[o] >> 4, tq = seg[o] & 15;
-                ++o;
-                if (tq > 3 || o + (pq ? 128 : 64) > segLen) { why = "bad quantisation table"; return false; }
-                for (int i = 0; i < 64; ++i) {
-                    quant[tq][kZigzag[i]] = pq ? static_cast<uint16_t>((seg[o] << 8) | seg[o + 1]) : seg[o];
-                    o += pq ? 2 : 1;
-                }
+    int width = 0, height = 0;
+    int restartInterval = 0, hMax = 1, vMax = 1, mcusX = 0, mcusY = 0;
+    bool haveFrame = false, progressive = false, keepCoefficients = false, sawScan = false;
+
+    Decoder(const unsigned char *d, size_t n, std::string &w) : data(d), size(n), why(w) {}
+
+    bool fail(const char *message) {
+        why = message;
+        return false;
+    }
+
+    bool readQuantTables(const unsigned char *seg, size_t segLen) {
+        size_t o = 0;
+        while (o < segLen) {
+            const int pq = seg[o] >> 4, tq = seg[o] & 15;
+            ++o;
+            if (tq > 3 || o + (pq ? 128 : 64) > segLen) return fail("bad quantisation table");
+            for (int i = 0; i < 64; ++i) {
+                quant[tq][kZigzag[i]] = pq ? static_cast<uint16_t>((seg[o] << 8) | seg[o + 1]) : seg[o];
+                o += pq ? 2 : 1;
             }
-        } else if (marker == 0xC4) {                        // Huffman tables
-            size_t o = 0;
-            while (o + 17 <= segLen) {
-                const int tc = seg[o] >> 4, th = seg[o] & 15;
-                if (tc > 1 || th > 3) { why = "bad Huffman table"; return false; }
-                Huffman &h = tc ? ac[th] : dc[th];
-                int total = 0, code = 0;
-                for (int l = 1; l <= 16; ++l) {
-                    h.count[l] = seg[o + l];
-                    h.firstIndex[l] = total;
-                    h.firstCode[l] = code;
-                    total += h.count[l];
-                    code = (code + h.count[l]) << 1;
-                }
-                o += 17;
-                if (total > 256 || o + total > segLen) { why = "bad Huffman table"; return false; }
-                std::memcpy(h.symbols, seg + o, static_cast<size_t>(total));
-                h.present = true;
-                o += total;
+        }
+        return true;
+    }
+
+    bool readHuffmanTables(const unsigned char *seg, size_t segLen) {
+        size_t o = 0;
+        while (o + 17 <= segLen) {
+            const int tc = seg[o] >> 4, th = seg[o] & 15;
+            if (tc > 1 || th > 3) return fail("bad Huffman table");
+            Huffman &h = tc ? ac[th] : dc[th];
+            int total = 0, code = 0;
+            for (int l = 1; l <= 16; ++l) {
+                h.count[l] = seg[o + l];
+                h.firstIndex[l] = total;
+                h.firstCode[l] = code;
+                total += h.count[l];
+                code = (code + h.count[l]) << 1;
             }
-        } else if (marker == 0xC0 || marker == 0xC1) {      // baseline / extended sequential frame
-            if (segLen < 6 || seg[0] != 8) { why = "only 8-bit samples are supported"; return false; }
-            height = (seg[1] << 8) | seg[2];
-            width = (seg[3] << 8) | seg[4];
-            // a header may claim 65535 x 65535; textures beyond 16384 x 16384 are refused, not allocated
-            if (width > 16384 || height > 16384) { why = "image larger than 16384 x 16384"; return false; }
-            const int n = seg[5];
-            if ((n != 1 && n != 3) || segLen < static_cast<size_t>(6 + 3 * n) || width <= 0 || height <= 0) {
-                why = "only greyscale and YCbCr images are supported";
-                return false;
-            }
-            comps.assign(static_cast<size_t>(n), Component());
-            for (int i = 0; i < n; ++i) {
-                Component &c = comps[static_cast<size_t>(i)];
-                c.id = seg[6 + 3 * i];
-                c.h = seg[7 + 3 * i] >> 4;
-                c.v = seg[7 + 3 * i] & 15;
-                c.tq = seg[8 + 3 * i];
-                if (c.h < 1 || c.h > 2 || c.v < 1 || c.v > 2 || c.tq > 3) { why = "unsupported sampling factors"; return false; }
-                if (n == 1) c.h = c.v = 1;   // a single component is never interleaved: one block per MCU
-                hMax = c.h > hMax ? c.h : hMax;
-                vMax = c.v > vMax ? c.v : vMax;
-            }
-            haveFrame = true;
-        } else if (marker == 0xC2 || (marker >= 0xC3 && marker <= 0xCF && marker != 0xC4 && marker != 0xC8 && marker != 0xCC)) {
-            why = marker == 0xC2 ? "progressive JPEG is not supported" : "unsupported JPEG coding process";
-            return false;
-        } else if (marker == 0xDD) {
-            if (segLen >= 2) restartInterval = (seg[0] << 8) | seg[1];
-        } else if (marker == 0xDA) {                        // scan: all components interleaved
-            if (!haveFrame) { why = "scan before frame header"; return false; }
-            const int n = seg[0];
-            if (n != static_cast<int>(comps.size()) || segLen < static_cast<size_t>(1 + 2 * n + 3)) {
-                why = "only single-scan (interleaved) files are supported";
-                return false;
-            }
-            for (int i = 0; i < n; ++i) {
-                Component *c = nullptr;
-                for (auto &k : comps)
-                    if (k.id == seg[1 + 2 * i]) c = &k;
-                if (!c) { why = "scan names an unknown component"; return false; }
-                c->td = seg[2 + 2 * i] >> 4;
-                c->ta = seg[2 + 2 * i] & 15;
-                if (c->td > 3 || c->ta > 3 || !dc[c->td].present || !ac[c->ta].present) { why = "missing Huffman table"; return false; }
-            }
-            const int mcuW = 8 * hMax, mcuH = 8 * vMax;
-            const int mcusX = (width + mcuW - 1) / mcuW, mcusY = (height + mcuH - 1) / mcuH;
-            for (auto &c : comps) {
-                c.blocksW = mcusX * c.h;
-                c.blocksH = mcusY * c.v;
-                c.plane.assign(static_cast<size_t>(c.blocksW) * 8 * c.blocksH * 8, 0);
-                c.dcPred = 0;
-            }
-            BitReader br{data + at + len, data + size};
-            int untilRestart = restartInterval;
-            short block[64];
-            for (int my = 0; my < mcusY; ++my) {
-                for (int mx = 0; mx < mcusX; ++mx) {
-                    for (auto &c : comps) {
-                        for (int by = 0; by < c.v; ++by) {
-                            for (int bx = 0; bx < c.h; ++bx) {
-                                std::memset(block, 0, sizeof block);
-                                const int t = decodeSymbol(br, dc[c.td]);
-                                if (t < 0 || t > 11) { why = "corrupt entropy-coded data"; return false; }
-                                c.dcPred += extend(br.get(t), t);
-                                block[0] = static_cast<short>(c.dcPred * quant[c.tq][0]);
-                                for (int k = 1; k < 64;) {
-                                    const int rs = decodeSymbol(br, ac[c.ta]);
-                                    if (rs < 0) { why = "corrupt entropy-coded data"; return false; }
-                                    const int run = rs >> 4, sz = rs & 15;
-                                    if (sz == 0) {
-                                        if (run != 15) break;   // end of block
-                                        k += 16;
-                                        continue;
-                                    }
-                                    k += run;
-                                    if (k > 63) { why = "corrupt entropy-coded data"; return false; }
-                                    const int z = kZigzag[k];
-                                    block[z] = static_cast<short>(extend(br.get(sz), sz) * quant[c.tq][z]);
-                                    ++k;
-                                }
-                                const int px = (mx * c.h + bx) * 8, py = (my * c.v + by) * 8;
-                                idctBlock(&c.plane[static_cast<size_t>(py) * c.blocksW * 8 + px], c.blocksW * 8, block);
-                            }
+            o += 17;
+            if (total > 256 || o + total > segLen) return fail("bad Huffman table");
+            std::memcpy(h.symbols, seg + o, static_cast<size_t>(total));
+            h.present = true;
+            o += total;
+        }
+        return true;
+    }
+
+    bool readFrame(const unsigned char *seg, size_t segLen, bool isProgressive) {
+        if (haveFrame) return fail("second frame header");
+        if (segLen < 6 || seg[0] != 8) return fail("only 8-bit samples are supported");
+        height = (seg[1] << 8) | seg[2];
+        width = (seg[3] << 8) | seg[4];
+        // a header may claim 65535 x 65535; textures beyond 16384 x 16384 are refused, not allocated
+        if (width > 16384 || height > 16384) return fail("image larger than 16384 x 16384");
+        const int n = seg[5];
+        if ((n != 1 && n != 3) || segLen < static_cast<size_t>(6 + 3 * n) || width <= 0 || height <= 0)
+            return fail("only greyscale and YCbCr images are supported");
+        comps.assign(static_cast<size_t>(n), Component());
+        for (int i = 0; i < n; ++i) {
+            Component &c = comps[static_cast<size_t>(i)];
+            c.id = seg[6 + 3 * i];
+            c.h = seg[7 + 3 * i] >> 4;
+            c.v = seg[7 + 3 * i] & 15;
+            c.tq = seg[8 + 3 * i];
+            if (c.h < 1 || c.h > 2 || c.v < 1 || c.v > 2 || c.tq > 3) return fail("unsupported sampling factors");
+            if (n == 1) c.h = c.v = 1;   // a single component is never interleaved: one block per MCU
+            hMax = c.h > hMax ? c.h : hMax;
+            vMax = c.v > vMax ? c.v : vMax;
+        }
+        const int mcuW = 8 * hMax, mcuH = 8 * vMax;
+        mcusX = (width + mcuW - 1) / mcuW;
+        mcusY = (height + mcuH - 1) / mcuH;
+        for (auto &c : comps) {
+            c.blocksW = mcusX * c.h;
+            c.blocksH = mcusY * c.v;
+            c.blocksAcross = ((width * c.h + hMax - 1) / hMax + 7) / 8;
+            c.blocksDown = ((height * c.v + vMax - 1) / vMax + 7) / 8;
+            c.plane.assign(static_cast<size_t>(c.blocksW) * 8 * c.blocksH * 8, 0);
+        }
+        progressive = isProgressive;
+        haveFrame = true;
+        return true;
+    }
+
+    void storeBlock(Component &c, int bx, int by, const short *coefficients) {
+        short block[64];
+        for (int z = 0; z < 64; ++z) block[z] = static_cast<short>(coefficients[z] * quant[c.tq][z]);
+        idctBlock(&c.plane[static_cast<size_t>(by) * 8 * c.blocksW * 8 + static_cast<size_t>(bx) * 8], c.blocksW * 8, block);
+    }
+
+    // Decodes the entropy-coded segment that starts at `from`; returns where it stopped reading.
+    bool readScan(const unsigned char *seg, size_t segLen, const unsigned char *from, const unsigned char *&stoppedAt) {
+        if (!haveFrame) return fail("scan before frame header");
+        const int n = segLen ? seg[0] : 0;
+        if (n < 1 || n > static_cast<int>(comps.size()) || segLen < static_cast<size_t>(1 + 2 * n + 3)) return fail("bad scan header");
+        std::vector<Component *> inScan;
+        for (int i = 0; i < n; ++i) {
+            Component *c = nullptr;
+            for (auto &k : comps)
+                if (k.id == seg[1 + 2 * i]) c = &k;
+            if (!c) return fail("scan names an unknown component");
+            for (Component *earlier : inScan)
+                if (earlier == c) return fail("scan names a component twice");
+            c->td = seg[2 + 2 * i] >> 4;
+            c->ta = seg[2 + 2 * i] & 15;
+            if (c->td > 3 || c->ta > 3) return fail("bad Huffman table selector");
+            inScan.push_back(c);
+        }
+        Scan sc;
+        sc.ss = seg[1 + 2 * n];
+        sc.se = seg[2 + 2 * n];
+        sc.ah = seg[3 + 2 * n] >> 4;
+        sc.al = seg[3 + 2 * n] & 15;
+        if (progressive) {
+            if (sc.ss > 63 || sc.se > 63 || sc.ss > sc.se || sc.ah > 13 || sc.al > 13) return fail("bad progressive scan parameters");
+            if ((sc.ss == 0) != (sc.se == 0)) return fail("bad progressive scan parameters");   // DC and AC never share a scan
+            if (sc.ss > 0 && n != 1) return fail("bad progressive scan parameters");            // AC scans cover one component
+        } else {
+            sc.ss = 0;
+            sc.se = 63;
+            sc.ah = sc.al = 0;
+        }
+        for (Component *c : inScan) {
+            const bool needsDC = sc.ss == 0 && sc.ah == 0, needsAC = sc.se > 0;
+            if ((needsDC && !dc[c->td].present) || (needsAC && !ac[c->ta].present)) return fail("missing Huffman table");
+        }
+        // A sequential file whose first scan carries every component goes straight to samples (and
+        // ends the decode); anything else collects coefficients until the end of the image.
+        const bool straightToSamples = !progressive && !sawScan && n == static_cast<int>(comps.size());
+        if (!straightToSamples && !keepCoefficients) {
+            keepCoefficients = true;
+            for (auto &c : comps) c.coef.assign(static_cast<size_t>(c.blocksW) * c.blocksH * 64, 0);
+        }
+        sawScan = true;
+        for (Component *c : inScan) c->dcPred = 0;
+
+        BitReader br{from, data + size};
+        const bool alone = n == 1;
+        const int unitsX = alone ? inScan[0]->blocksAcross : mcusX, unitsY = alone ? inScan[0]->blocksDown : mcusY;
+        int untilRestart = restartInterval;
+        short direct[64];
+        for (int uy = 0; uy < unitsY; ++uy) {
+            for (int ux = 0; ux < unitsX; ++ux) {
+                for (Component *c : inScan) {
+                    const int across = alone ? 1 : c->h, down = alone ? 1 : c->v;
+                    for (int j = 0; j < down; ++j) {
+                        for (int i = 0; i < across; ++i) {
+                            const int bx = ux * across + i, by = uy * down + j;
+                            short *block = direct;
+                            if (keepCoefficients) block = &c->coef[(static_cast<size_t>(by) * c->blocksW + bx) * 64];
+                            else std::memset(direct, 0, sizeof direct);
+                            bool ok;
+                            if (!progressive) ok = decodeSequentialBlock(br, dc[c->td], ac[c->ta], *c, block);
+                            else if (sc.ss == 0) ok = decodeProgressiveDC(br, dc[c->td], *c, sc, block);
+                            else if (sc.ah == 0) ok = decodeProgressiveACFirst(br, ac[c->ta], sc, block);
+                            else ok = decodeProgressiveACRefine(br, ac[c->ta], sc, block);
+                            if (!ok) return fail("corrupt entropy-coded data");
+                            if (!keepCoefficients) storeBlock(*c, bx, by, block);
                         }
                     }
-                    if (restartInterval && --untilRestart == 0 && !(my == mcusY - 1 && mx == mcusX - 1)) {
-                        // Skip to the restart marker; predictions and the bit buffer start afresh.
-                        const unsigned char *p = br.p;
-                        while (p + 1 < br.end && !(p[0] == 0xFF && p[1] >= 0xD0 && p[1] <= 0xD7)) ++p;
-                        if (p + 1 >= br.end) { why = "restart marker missing"; return false; }
-                        br.p = p + 2;
-                        br.reset();
-                        for (auto &c : comps) c.dcPred = 0;
-                        untilRestart = restartInterval;
-                    }
+                }
+                if (restartInterval && --untilRestart == 0 && !(uy == unitsY - 1 && ux == unitsX - 1)) {
+                    // Skip to the restart marker; predictions, end-of-band runs and the bit buffer start afresh.
+                    const unsigned char *p = br.p;
+                    while (p + 1 < br.end && !(p[0] == 0xFF && p[1] >= 0xD0 && p[1] <= 0xD7)) ++p;
+                    if (p + 1 >= br.end) return fail("restart marker missing");
+                    br.p = p + 2;
+                    br.reset();
+                    for (Component *c : inScan) c->dcPred = 0;
+                    sc.eobRun = 0;
+                    untilRestart = restartInterval;
                 }
             }
-            // Colour conversion at full resolution.
-            rgba.assign(static_cast<size_t>(width) * height * 4, 255);
-            std::vector<unsigned char> rows[3];
-            for (auto &r : rows) r.assign(static_cast<size_t>(mcusX) * mcuW + 16, 0);
-            for (int y = 0; y < height; ++y) {
-                for (size_t ci = 0; ci < comps.size(); ++ci) {
-                    const Component &c = comps[ci];
-                    const int hs = hMax / c.h, vs = vMax / c.v;
-                    const int planeW = c.blocksW * 8, planeH = c.blocksH * 8;
-                    const int wIn = (width + hs - 1) / hs;
-                    int nearY = y, farY = y;
-                    if (vs == 2) {   // rows y/2 and its neighbour on the side y lies towards
-                        nearY = y >> 1;
-                        farY = (y & 1) ? nearY + 1 : nearY - 1;
-                        const int last = (height + 1) / 2 - 1;
-                        if (farY < 0) farY = 0;
-                        if (farY > last) farY = last;
-                    }
-                    if (nearY >= planeH) nearY = planeH - 1;
-                    if (farY >= planeH) farY = planeH - 1;
-                    upsampleRow(rows[ci].data(), &c.plane[static_cast<size_t>(nearY) * planeW], &c.plane[static_cast<size_t>(farY) * planeW], wIn, hs, vs);
-                }
-                unsigned char *out = &rgba[static_cast<size_t>(y) * width * 4];
-                if (comps.size() == 1) {
-                    for (int x = 0; x < width; ++x) out[x * 4] = out[x * 4 + 1] = out[x * 4 + 2] = rows[0][static_cast<size_t>(x)];
-                } else {
-                    for (int x = 0; x < width; ++x) {
-                        const int yFixed = (rows[0][static_cast<size_t>(x)] << 20) + (1 << 19);
-                        const int cb = rows[1][static_cast<size_t>(x)] - 128, cr = rows[2][static_cast<size_t>(x)] - 128;
-                        const int r = yFixed + cr * (static_cast<int>(1.40200f * 4096.0f + 0.5f) << 8);
-                        const int g = yFixed + cr * -(static_cast<int>(0.71414f * 4096.0f + 0.5f) << 8) +
-                                      static_cast<int>((static_cast<unsigned>(cb * -(static_cast<int>(0.34414f * 4096.0f + 0.5f) << 8))) & 0xffff0000u);
-                        const int b = yFixed + cb * (static_cast<int>(1.77200f * 4096.0f + 0.5f) << 8);
-                        out[x * 4 + 0] = clamp255(r >> 20);
-                        out[x * 4 + 1] = clamp255(g >> 20);
-                        out[x * 4 + 2] = clamp255(b >> 20);
-                    }
-                }
-            }
-            return true;
         }
-        at += len;
+        stoppedAt = br.p;
+        return true;
     }
-    why = "no image data found";
-    return false;
+
+    // Samples of every component from the collected coefficients.
+    void finishCoefficients() {
+        for (auto &c : comps)
+            for (int by = 0; by < c.blocksH; ++by)
+                for (int bx = 0; bx < c.blocksW; ++bx) storeBlock(c, bx, by, &c.coef[(static_cast<size_t>(by) * c.blocksW + bx) * 64]);
+    }
+
+    // Colour conversion at full resolution.
+    void toRGBA(std::vector<unsigned char> &rgba) const {
+        const int mcuW = 8 * hMax;
+        rgba.assign(static_cast<size_t>(width) * height * 4, 255);
+        std::vector<unsigned char> rows[3];
+        for (auto &r : rows) r.assign(static_cast<size_t>(mcusX) * mcuW + 16, 0);
+        for (int y = 0; y < height; ++y) {
+            for (size_t ci = 0; ci < comps.size(); ++ci) {
+                const Component &c = comps[ci];
+                const int hs = hMax / c.h, vs = vMax / c.v;
+                const int planeW = c.blocksW * 8, planeH = c.blocksH * 8;
+                const int wIn = (width + hs - 1) / hs;
+                int nearY = y, farY = y;
+                if (vs == 2) {   // rows y/2 and its neighbour on the side y lies towards
+                    nearY = y >> 1;
+                    farY = (y & 1) ? nearY + 1 : nearY - 1;
+                    const int last = (height + 1) / 2 - 1;
+                    if (farY < 0) farY = 0;
+                    if (farY > last) farY = last;
+                }
+                if (nearY >= planeH) nearY = planeH - 1;
+                if (farY >= planeH) farY = planeH - 1;
+                upsampleRow(rows[ci].data(), &c.plane[static_cast<size_t>(nearY) * planeW], &c.plane[static_cast<size_t>(farY) * planeW], wIn, hs, vs);
+            }
+            unsigned char *out = &rgba[static_cast<size_t>(y) * width * 4];
+            if (comps.size() == 1) {
+                for (int x = 0; x < width; ++x) out[x * 4] = out[x * 4 + 1] = out[x * 4 + 2] = rows[0][static_cast<size_t>(x)];
+            } else {
+                for (int x = 0; x < width; ++x) {
+                    const int yFixed = (rows[0][static_cast<size_t>(x)] << 20) + (1 << 19);
+                    const int cb = rows[1][static_cast<size_t>(x)] - 128, cr = rows[2][static_cast<size_t>(x)] - 128;
+                    const int r = yFixed + cr * (static_cast<int>(1.40200f * 4096.0f + 0.5f) << 8);
+                    const int g = yFixed + cr * -(static_cast<int>(0.71414f * 4096.0f + 0.5f) << 8) +
+                                  static_cast<int>((static_cast<unsigned>(cb * -(static_cast<int>(0.34414f * 4096.0f + 0.5f) << 8))) & 0xffff0000u);
+                    const int b = yFixed + cb * (static_cast<int>(1.77200f * 4096.0f + 0.5f) << 8);
+                    out[x * 4 + 0] = clamp255(r >> 20);
+                    out[x * 4 + 1] = clamp255(g >> 20);
+                    out[x * 4 + 2] = clamp255(b >> 20);
+                }
+            }
+        }
+    }
+
+    bool run(std::vector<unsigned char> &rgba) {
+        if (size < 4 || data[0] != 0xFF || data[1] != 0xD8) return fail("not a JPEG stream");
+        size_t at = 2;
+        while (at + 2 <= size) {
+            if (data[at] != 0xFF) return fail("marker expected");
+            while (at < size && data[at] == 0xFF) ++at;   // fill bytes
+            if (at >= size) break;
+            const int marker = data[at++];
+            if (marker == 0xD9) break;
+            if (marker == 0x01 || (marker >= 0xD0 && marker <= 0xD7)) continue;
+            if (at + 2 > size) break;
+            const size_t len = (static_cast<size_t>(data[at]) << 8) | data[at + 1];
+            if (len < 2 || at + len > size) return fail("truncated segment");
+            const unsigned char *seg = data + at + 2;
+            const size_t segLen = len - 2;
+            at += len;
+            if (marker == 0xDB) {
+                if (!readQuantTables(seg, segLen)) return false;
+            } else if (marker == 0xC4) {
+                if (!readHuffmanTables(seg, segLen)) return false;
+            } else if (marker == 0xC0 || marker == 0xC1 || marker == 0xC2) {
+                if (!readFrame(seg, segLen, marker == 0xC2)) return false;
+            } else if (marker >= 0xC3 && marker <= 0xCF && marker != 0xC8 && marker != 0xCC) {
+                return fail("unsupported JPEG coding process");
+            } else if (marker == 0xDD) {
+                if (segLen >= 2) restartInterval = (seg[0] << 8) | seg[1];
+            } else if (marker == 0xDA) {
+                const unsigned char *stoppedAt = nullptr;
+                if (!readScan(seg, segLen, data + at, stoppedAt)) return false;
+                if (!keepCoefficients) break;   // the one scan of a sequential file: samples are in place
+                // Next marker after the entropy-coded bytes (stuffed zeros and restart markers belong to them).
+                size_t p = static_cast<size_t>(stoppedAt - data);
+                while (p + 1 < size && !(data[p] == 0xFF && data[p + 1] != 0x00 && data[p + 1] != 0xFF && !(data[p + 1] >= 0xD0 && data[p + 1] <= 0xD7))) ++p;
+                at = p;
+            }
+        }
+        if (!sawScan) return fail("no image data found");
+        if (keepCoefficients) finishCoefficients();
+        toRGBA(rgba);
+        return true;
+    }
+};
+
+}  // namespace
+
+bool DecodeJpegRGBA(const unsigned char *data, size_t size, int &width, int &height, std::vector<unsigned char> &rgba, std::string &why) {
+    Decoder decoder(data, size, why);
+    if (!decoder.run(rgba)) return false;
+    width = decoder.width;
+    height = decoder.height;
+    return true;
 }
 
 }  // namespace imageio

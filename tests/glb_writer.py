@@ -127,6 +127,71 @@ def png_bytes(array, mode=None, **save_kw):
     return buf.getvalue()
 
 
+def raw_png(samples, color_type, bit_depth, interlace=False, palette=None, trns=None, filter_type=0):
+    """A PNG stream written from scratch: `samples` is (h, w, channels) of integers below
+    2**bit_depth, rows top-down.  Covers what an imaging library will not write: low bit depths,
+    16-bit colour, Adam7 interlacing, colour-key transparency, a chosen row filter (0..4)."""
+    import struct
+    import zlib
+    samples = np.asarray(samples)
+    h, w, ch = samples.shape
+
+    def chunk(kind, body):
+        return struct.pack(">I", len(body)) + kind + body + struct.pack(">I", zlib.crc32(kind + body))
+
+    def pack_rows(sub):
+        rows = []
+        bpp = max(1, ch * bit_depth // 8)
+        prev = None
+        for r in sub:
+            flat = r.reshape(-1)
+            if bit_depth == 16:
+                line = flat.astype(">u2").tobytes()
+            elif bit_depth == 8:
+                line = flat.astype(np.uint8).tobytes()
+            else:
+                bits = np.zeros(((len(flat) * bit_depth + 7) // 8) * 8, np.uint8)
+                for k in range(bit_depth):
+                    bits[np.arange(len(flat)) * bit_depth + k] = (flat >> (bit_depth - 1 - k)) & 1
+                line = np.packbits(bits).tobytes()
+            cur = np.frombuffer(line, np.uint8).astype(np.int32)
+            up = prev if prev is not None else np.zeros_like(cur)
+            left = np.concatenate([np.zeros(bpp, np.int32), cur[:-bpp]]) if len(cur) > bpp else np.zeros_like(cur)
+            if len(cur) <= bpp:
+                left = np.zeros_like(cur)
+            upleft = np.concatenate([np.zeros(bpp, np.int32), up[:-bpp]]) if len(cur) > bpp else np.zeros_like(cur)
+            if filter_type == 0:
+                pred = np.zeros_like(cur)
+            elif filter_type == 1:
+                pred = left
+            elif filter_type == 2:
+                pred = up
+            elif filter_type == 3:
+                pred = (left + up) // 2
+            else:
+                pa, pb, pc = np.abs(up - upleft), np.abs(left - upleft), np.abs(left + up - 2 * upleft)
+                pred = np.where((pa <= pb) & (pa <= pc), left, np.where(pb <= pc, up, upleft))
+            rows.append(bytes([filter_type]) + ((cur - pred) & 255).astype(np.uint8).tobytes())
+            prev = cur
+        return b"".join(rows)
+
+    if interlace:
+        lattice = [(0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)]
+        raw = b"".join(pack_rows(samples[y0::dy, x0::dx]) for x0, y0, dx, dy in lattice
+                       if samples[y0::dy, x0::dx].size)
+    else:
+        raw = pack_rows(samples)
+    out = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, bit_depth, color_type, 0, 0, 1 if interlace else 0))
+    if palette is not None:
+        out += chunk(b"PLTE", np.asarray(palette, np.uint8).tobytes())
+    if trns is not None:
+        out += chunk(b"tRNS", bytes(trns))
+    half = len(raw) // 2 if len(raw) > 8 else len(raw)
+    packed = zlib.compress(raw, 6)
+    out += chunk(b"IDAT", packed[:len(packed) // 2]) + chunk(b"IDAT", packed[len(packed) // 2:])   # split across two chunks
+    return out + chunk(b"IEND", b"")
+
+
 def quat_matrix(q):
     """Rotation matrix of a unit quaternion given as glTF stores it, (x, y, z, w)."""
     x, y, z, w = q

@@ -272,18 +272,163 @@ def test_jpeg_textures_are_close_to_an_independent_decoder(tmp_path, case):
     assert diff.max() <= 4 and diff.mean() <= 0.6, (diff.max(), diff.mean())
 
 
-def test_progressive_jpeg_is_refused_with_an_empty_texture(tmp_path):
-    from PIL import Image
-    import io
-    buf = io.BytesIO()
-    Image.fromarray(np.full((16, 16, 3), 90, np.uint8), "RGB").save(buf, format="JPEG", progressive=True)
+def _texture_of(tmp_path, image_bytes, name="img.glb"):
     b = GlbBuilder()
-    t = b.texture(buf.getvalue())
+    t = b.texture(image_bytes)
     m = b.material(pbrMetallicRoughness={"baseColorTexture": {"index": t}})
     p, n, uv, i = quad([0, 0, 0], [1, 0, 0], [0, 1, 0])
     b.node(mesh=b.mesh([b.primitive(p, i, m, normals=n, uvs=uv)]), root=True)
-    tex = load(b.write(tmp_path / "prog.glb")).streams[5]
-    assert tex.size == 5 and list(i32(tex[:3])) == [0, 0, 0]      # header only, no texels
+    tex = load(b.write(tmp_path / name)).streams[5]
+    w, h, ch = (int(v) for v in i32(tex[:3]))
+    return w, h, ch, np.round(tex[5:].reshape(h, w, 4) * 255).astype(np.int32) if w * h else None
+
+
+PROGRESSIVE_CASES = {
+    "444": dict(quality=90, subsampling=0),
+    "422": dict(quality=80, subsampling=1),
+    "420": dict(quality=92, subsampling=2),
+    "420_restart": dict(quality=60, subsampling=2, restart_marker_blocks=2),
+    "grey": dict(quality=85),
+    "444_q100": dict(quality=100, subsampling=0),
+    "420_q15": dict(quality=15, subsampling=2),
+}
+
+
+@pytest.mark.parametrize("case", sorted(PROGRESSIVE_CASES))
+def test_progressive_jpeg_decodes_to_the_same_texels_as_its_sequential_twin(tmp_path, case):
+    """A progressive file carries the same quantised coefficients as the sequential file of the same
+    encoder settings, only in another order (DC first, spectral bands, successive-approximation
+    refinements, end-of-band runs): both must decode to identical texels, and close to libjpeg's."""
+    from PIL import Image
+    import io
+    rng = np.random.default_rng(23)
+    w, h = 83, 61
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = np.stack([128 + 110 * np.sin(xx / 6.0 + yy / 9.0), 128 + 100 * np.cos(yy / 3.0), (xx * 5 + yy * 11) % 256], -1)
+    img = np.clip(img + rng.normal(0, 10, img.shape), 0, 255).astype(np.uint8)
+    img[20:40, 30:60] = rng.integers(0, 255, (20, 30, 3))        # busy patch: long refinement runs
+    pil = Image.fromarray(img, "RGB")
+    if case == "grey":
+        pil = pil.convert("L")
+    streams = {}
+    for progressive in (False, True):
+        buf = io.BytesIO()
+        pil.save(buf, format="JPEG", progressive=progressive, **PROGRESSIVE_CASES[case])
+        streams[progressive] = buf.getvalue()
+    assert b"\xff\xc2" in streams[True] and b"\xff\xc2" not in streams[False]
+    ws, hs, _, sequential = _texture_of(tmp_path, streams[False], "seq.glb")
+    wp, hp, _, progressive = _texture_of(tmp_path, streams[True], "prog.glb")
+    assert (ws, hs, wp, hp) == (w, h, w, h)
+    assert np.array_equal(progressive, sequential)
+    expect = np.asarray(Image.open(io.BytesIO(streams[True])).convert("RGBA"), np.int32)
+    diff = np.abs(progressive - expect)
+    assert diff.max() <= 5 and diff.mean() <= 0.7, (diff.max(), diff.mean())
+
+
+def test_truncated_progressive_jpeg_does_not_crash(tmp_path):
+    from PIL import Image
+    import io
+    rng = np.random.default_rng(2)
+    buf = io.BytesIO()
+    Image.fromarray(rng.integers(0, 255, (40, 40, 3), dtype=np.uint8), "RGB").save(buf, format="JPEG", progressive=True, quality=80)
+    whole = buf.getvalue()
+    for cut in (len(whole) // 3, len(whole) // 2, len(whole) - 3):
+        w, h, _, texels = _texture_of(tmp_path, whole[:cut], "cut.glb")
+        assert (w, h) in ((40, 40), (0, 0))      # either what the scans so far give, or refused
+
+
+PNG_FORMS = [
+    # (colour type, bit depth, channels)
+    (0, 1, 1), (0, 2, 1), (0, 4, 1), (0, 8, 1), (0, 16, 1),
+    (2, 8, 3), (2, 16, 3), (3, 1, 1), (3, 2, 1), (3, 4, 1), (3, 8, 1),
+    (4, 8, 2), (4, 16, 2), (6, 8, 4), (6, 16, 4),
+]
+
+
+def _png_expectation(samples, color_type, depth, palette, trns):
+    h, w, ch = samples.shape
+    to8 = (lambda v: v >> 8) if depth == 16 else (lambda v: v * {1: 255, 2: 85, 4: 17, 8: 1}[depth])
+    out = np.full((h, w, 4), 255, np.int32)
+    if color_type == 3:
+        out[..., :3] = np.asarray(palette)[samples[..., 0]]
+        if trns is not None:
+            alpha = np.full(256, 255)
+            alpha[:len(trns)] = list(trns)
+            out[..., 3] = alpha[samples[..., 0]]
+    elif color_type in (0, 4):
+        out[..., :3] = to8(samples[..., :1])
+        if color_type == 4:
+            out[..., 3] = to8(samples[..., 1])
+    else:
+        out[..., :3] = to8(samples[..., :3])
+        if color_type == 6:
+            out[..., 3] = to8(samples[..., 3])
+    return out
+
+
+@pytest.mark.parametrize("interlace", [False, True])
+@pytest.mark.parametrize("form", PNG_FORMS, ids=lambda f: "type%d_%dbit" % f[:2])
+def test_png_of_every_colour_type_depth_and_interlace(tmp_path, form, interlace):
+    """Every colour type / bit depth pair of the PNG standard, plain and Adam7-interlaced, every row
+    filter: texels are the samples scaled to 8 bits (16-bit: the high byte)."""
+    from glb_writer import raw_png
+    from PIL import Image
+    import io
+    color_type, depth, ch = form
+    rng = np.random.default_rng(color_type * 100 + depth)
+    w, h = 19, 11                       # not multiples of 8: ragged Adam7 passes and partial bytes
+    samples = rng.integers(0, 2 ** depth, (h, w, ch))
+    samples[3:6] = (np.arange(w)[None, :, None] * 3 + np.arange(3)[:, None, None]) % (2 ** depth)
+    palette = rng.integers(0, 256, (2 ** depth, 3)) if color_type == 3 else None
+    trns = bytes(rng.integers(0, 256, 2 ** depth // 2 + 1).tolist()) if color_type == 3 else None
+    for filter_type in range(5):
+        stream = raw_png(samples, color_type, depth, interlace, palette, trns, filter_type)
+        gw, gh, gch, got = _texture_of(tmp_path, stream)
+        assert (gw, gh, gch) == (w, h, 4)
+        assert np.array_equal(got, _png_expectation(samples, color_type, depth, palette, trns)), filter_type
+    if depth == 8:      # the writer above against an independent reader
+        assert np.array_equal(np.asarray(Image.open(io.BytesIO(stream)).convert("RGBA"), np.int32), got)
+
+
+@pytest.mark.parametrize("interlace", [False, True])
+@pytest.mark.parametrize("color_type,depth", [(0, 2), (0, 8), (0, 16), (2, 8), (2, 16)])
+def test_png_colour_key_makes_matching_pixels_transparent(tmp_path, color_type, depth, interlace):
+    from glb_writer import raw_png
+    rng = np.random.default_rng(9)
+    ch = 1 if color_type == 0 else 3
+    samples = rng.integers(0, 2 ** depth, (9, 10, ch))
+    key = samples[4, 7].copy()
+    samples[1, 2] = key
+    near = key.copy()
+    near[-1] ^= 1                       # differs in the lowest bit only: not transparent, even at 16 bits
+    samples[6, 3] = near
+    trns = b"".join(int(v).to_bytes(2, "big") for v in key)
+    _, _, _, got = _texture_of(tmp_path, raw_png(samples, color_type, depth, interlace, trns=trns))
+    expect = _png_expectation(samples, color_type, depth, None, None)
+    expect[..., 3] = np.where((samples == key).all(-1), 0, 255)
+    assert expect[1, 2, 3] == 0 and expect[4, 7, 3] == 0 and expect[6, 3, 3] == 255
+    assert np.array_equal(got, expect)
+
+
+@pytest.mark.parametrize("size", [(1, 1), (2, 3), (5, 1), (1, 9), (8, 8), (9, 17)])
+def test_interlaced_png_with_empty_passes(tmp_path, size):
+    """Images narrower or shorter than the Adam7 lattice have passes without any pixel."""
+    from glb_writer import raw_png
+    w, h = size
+    samples = np.random.default_rng(w * 31 + h).integers(0, 256, (h, w, 4))
+    gw, gh, _, got = _texture_of(tmp_path, raw_png(samples, 6, 8, True, filter_type=4))
+    assert (gw, gh) == (w, h) and np.array_equal(got, samples)
+
+
+def test_png_outside_the_standard_is_refused(tmp_path):
+    from glb_writer import raw_png
+    samples = np.zeros((4, 4, 3), np.int64)
+    for stream in (raw_png(samples, 2, 4),                       # RGB has no 4-bit form
+                   raw_png(samples[..., :1], 3, 16, palette=np.zeros((2, 3))),
+                   raw_png(samples, 2, 8)[:-40],                 # data cut short
+                   raw_png(samples, 2, 8, filter_type=0).replace(b"IDAT", b"IDAX")):
+        w, h, _, _ = _texture_of(tmp_path, stream)
+        assert (w, h) == (0, 0)
 
 
 # ---- hostile files: the loader is the trust boundary for external data --------------------------

@@ -216,3 +216,27 @@ def test_host_layer_hands_backend_errors_on_instead_of_trapping():
     finally:
         capi.host.rth_engine_free(eng)
     assert not capi.host.rth_engine_create(b"cornell_quads", None, 0, pos, 90.0, 0.0, 50.0, 0, 24, 3, 1, capi.RT_TYPE_RGB, 0)
+
+
+def test_reserve_sizes_the_path_buffers_ahead_of_the_render(backend):
+    """rt_reserve before rt_set_frame is a state error; after it, the render call of that size finds
+    its buffers in place (same image as without the reservation)."""
+    W, H = 40, 32
+    b = capi.Backend(0)
+    try:
+        with pytest.raises(capi.RtError):
+            b.reserve(2)
+        scene = capi.Scene("cornell_knot", nu=32, nv=8)
+        cam = capi.make_camera(width=W, height=H, bounces=3, ray_per_pixel=4)
+        b.upload_scene(scene)
+        b.resize(W, H)
+        b.set_frame(cam, scene.sky, capi.RT_TYPE_RGB)
+        with pytest.raises(capi.RtError):
+            b.reserve(0)
+        b.reserve(3)
+        b.render(1, 3, 1)
+        got, n = b.readback()
+    finally:
+        b.close()
+    want, _ = OracleScene(scene).render(cam, capi.RT_TYPE_RGB, 1, 3, 1)
+    assert n == 3 and np.array_equal(got, want)
