@@ -8,6 +8,11 @@ using namespace rtd;
 
 namespace {
 
+// Waves per SIMD the counting instances are compiled for: their nine extra counters do not fit the
+// register budget of the plain instances (at 6-7 waves/SIMD the four-wide alpha-cut counting instance
+// spilled 64-68 bytes per lane and returned wrong images), and nobody times them.
+constexpr int kCountingWaves = 4;
+
 // ---- k_trace ----------------------------------------------------------------------------
 // RayBoundingBoxDst, src/RayScene.cpp:417-431, with 1/direction hoisted per ray.
 __device__ __forceinline__ float slabDistance(V3 bmin, V3 bmax, V3 ro, V3 inv, float t) {
@@ -223,7 +228,7 @@ __device__ __forceinline__ void intersectPrimitives(const SceneView &sc, LaneRay
 // ray but slower, because lanes then mix the small models' leaves with the large model's inner
 // nodes and the two phases of the loop run emptier.)
 template <bool COUNT, int STACK, bool ALPHA, bool PRIMS, bool ROOTS, bool WIDE, bool RETRACE = false>
-__global__ __launch_bounds__(kBlock, WIDE ? (ALPHA ? RT_WWIDE_ALPHA : RT_WWIDE)
+__global__ __launch_bounds__(kBlock, COUNT ? kCountingWaves : WIDE ? (ALPHA ? RT_WWIDE_ALPHA : RT_WWIDE)
                                           : (STACK <= 20 ? (ALPHA ? RT_WALPHA : PRIMS ? 7 : RT_W20) : STACK <= 24 ? (ALPHA ? (RT_WALPHA < 6 ? RT_WALPHA : 6) : 6) : 5)) void k_trace(SceneView sc, PathBuffers pb, int extParity, int stage, int refillLanes, int innerShare) {
     __shared__ int32_t stackLds[kBlock / 64][STACK][64];
     // ROOTS variants (scenes with more than two models): the models' root references sit in LDS.
