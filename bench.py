@@ -35,6 +35,7 @@ TREES = {   # RT_OPT_WIDE_BVH
     1: "four-wide trees collapsed from the uploaded trees (closest hits; the other triangle of a distance tie may win)",
     2: "the library's four-wide SAH trees (closest hits; the other triangle of a distance tie may win)",
     3: "the library's four-wide SAH trees, rays that met a distance tie traced again in the reference's order (library default)",
+    4: "the library's eight-wide SAH trees, rays that met a distance tie traced again in the reference's order",
 }
 
 
@@ -52,7 +53,7 @@ def parse():
     ap.add_argument("--tex-size", type=int, default=0, help="texture edge of the textured scenes (0 = scene default)")
     ap.add_argument("--bvh", choices=["reference", "sah"], default="reference",
                     help="tree builder: the reference's median split (default; the only mode whose traversal is the reference's) or the opt-in SAH build")
-    ap.add_argument("--wide", type=int, nargs="?", const=1, default=None, choices=[0, 1, 2, 3],
+    ap.add_argument("--wide", type=int, nargs="?", const=1, default=None, choices=[0, 1, 2, 3, 4],
                     help="trees the rays walk (RT_OPT_WIDE_BVH; default: the library's, 3): 0 = the uploaded trees in the reference's visiting order, "
                          "1 = four-wide trees from the uploaded trees, 2 = from the library's own SAH trees (1 and 2: closest hits, but the other triangle of a distance tie may win), "
                          "3 = as 2 with rays that met a distance tie traced again in the reference's order")

@@ -63,10 +63,10 @@ typedef struct rt_stats {
     uint64_t tri_tests;     /* ray/triangle tests (only if counters enabled) */
     uint64_t shaded_hits;   /* hits whose material was resolved */
     double trace_ms;        /* device time in the traversal kernel (HIP events) */
-    double total_ms;        /* device time of rt_render as a whole */
+    double total_ms;        /* device time of rt_render as a whole, summed over calls (calls that overlap on the device count in full each) */
     uint64_t trace_launches;
     uint64_t max_stack;     /* most traversal-stack entries any ray held (only if counters enabled) */
-    uint64_t retraced;      /* RT_OPT_WIDE_BVH 3: rays traced a second time, in the reference's order, after a distance tie */
+    uint64_t retraced;      /* RT_OPT_WIDE_BVH 3 and 4: rays traced a second time, in the reference's order, after a distance tie */
     /* Occupancy of the traversal kernel's lanes (only if counters enabled).  A wave of 64 lanes runs
      * one phase per step, inner nodes or leaves; a lane does work in a step if it opens a node or a
      * leaf in it: lane utilisation = (node_visits + leaf_visits) / (64 * wave_steps). */
@@ -105,7 +105,13 @@ int rt_set_frame(rt_ctx *ctx, const rt_camera *cam, const float sky_linear[3], i
 /* RayTracer::renderToTexture + the full-screen draw (src/RayTracer.cpp:1428-1452,
  * src/RayEngine.cpp:28-42) for frameCount = first_frame .. first_frame+n_frames-1
  * in steps of frame_stride (sample-split sharding uses stride = number of GPUs).
- * Adds each frame's colour into the sum buffer.  Asynchronous on the context's stream. */
+ * Adds each frame's colour into the sum buffer.  Asynchronous: the call queues its kernels and
+ * returns.  Calls of few paths (up to 4 Mi: one progressive frame of a viewer, as the reference's main
+ * loop issues them, src/main.cpp:163-202) are queued on three streams in turn, each with path
+ * buffers of its own, so that consecutive calls overlap on the device; the passes that add to the sum
+ * buffer are chained in call order, so the buffer holds the same bits as without the overlap
+ * (RT_OPT_PIPELINE).  Every other entry point that reads or writes the sum buffer takes its place in
+ * that order too. */
 int rt_render(rt_ctx *ctx, uint32_t first_frame, uint32_t n_frames, uint32_t frame_stride);
 
 /* Allocates now the per-path device memory that rt_render(first, n_frames, stride) would need
@@ -119,7 +125,7 @@ int rt_reserve(rt_ctx *ctx, uint32_t n_frames);
 /* RayTracer::reset (src/RayTracer.cpp:1467-1470): zero the sum buffer and frame count. */
 int rt_reset_accum(rt_ctx *ctx);
 
-/* Blocks until all queued work on the context's stream is complete. */
+/* Blocks until all work the context has queued, on any of its streams, is complete. */
 int rt_sync(rt_ctx *ctx);
 
 /* Reads the sum buffer (W*H*4 floats, row 0 = bottom row as gl_FragCoord) and the
@@ -236,8 +242,13 @@ int rt_set_counters(rt_ctx *ctx, int enabled);
  *                            reference-order kernel over the uploaded trees, whose answer replaces
  *                            the first (rt_stats.retraced counts such rays; 4 bytes of device
  *                            memory per ray slot hold the list).
+ *                            4: as 3 on eight-wide trees (80-byte nodes, children visited by the
+ *                            ray's direction octant, no sorting): two thirds of the node visits of 3
+ *                            but about twice the arithmetic per node, 7-19 % slower than 3 on every
+ *                            workload measured; kept as an option.  Scenes with alpha-cut
+ *                            textures walk the four-wide trees under this value.
  *                            The uploaded node section is validated for every value.  Values 2
- *                            and 3 need finite coordinates within 1e15: left at the default such a
+ *                            to 4 need finite coordinates within 1e15: left at the default such a
  *                            scene is walked as with 0; chosen by this option or by the
  *                            environment variable RT_WIDE_BVH the commit fails with RT_ERR_SCENE.
  *                            Scenes without triangles are not affected.
@@ -254,10 +265,13 @@ int rt_set_counters(rt_ctx *ctx, int enabled);
  *                            rayPerPixel unstratified samples per frame (not floor(sqrt)^2), jitter
  *                            over one pixel, plain mean.  Default 1 (`#if 1`, :569-583).  The
  *                            Spectral shader has no such branch and ignores it.  Call rt_set_frame
- *                            again after changing it. */
+ *                            again after changing it.
+ *   RT_OPT_PIPELINE          1 (default): small render calls overlap on the device, see rt_render.
+ *                            0: every call runs on the context's one stream, after the call before
+ *                            it (also: environment variable RT_PIPELINE=0).  Same output either way. */
 enum { RT_OPT_SHADOW_EARLY_OUT = 1, RT_OPT_REFILL_LANES = 2, RT_OPT_INNER_SHARE = 3, RT_OPT_MAX_PATHS = 4, RT_OPT_TILE_MAJOR = 5,
        RT_OPT_SPECTRAL_PDF_AS_WRITTEN = 6, RT_OPT_WIDE_BVH = 7, RT_OPT_HERO_WAVELENGTH = 8, RT_OPT_NEE = 9,
-       RT_OPT_STRATIFIED = 10 };
+       RT_OPT_STRATIFIED = 10, RT_OPT_PIPELINE = 11 };
 int rt_set_option(rt_ctx *ctx, int option, int value);
 
 const char *rt_strerror(int status);

@@ -19,6 +19,7 @@ RT_OPT_WIDE_BVH = 7
 RT_OPT_HERO_WAVELENGTH = 8
 RT_OPT_NEE = 9
 RT_OPT_STRATIFIED = 10
+RT_OPT_PIPELINE = 11
 
 # Every symbol include/rt_hip.h declares.
 HIP_SYMBOLS = [

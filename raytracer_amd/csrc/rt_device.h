@@ -38,6 +38,22 @@ struct __attribute__((aligned(64))) WideNode {
 };
 static_assert(sizeof(WideNode) == 64, "wide node must be one 64-byte line");
 
+// Eight-wide node (RT_OPT_WIDE_BVH 4), 80 bytes = five 16-byte loads.  Child boxes as in WideNode,
+// on a grid of cell size 2^(e-127) per axis.  Slot k (0..7) is described by byte k of `meta`:
+//   0                    empty slot (its box is inverted: lo 255, hi 0)
+//   0x38 + k             inner child: node number childBase + (number of inner slots below k)
+//   (2^n - 1) << 5 | f   leaf of n (1..3) triangles at wtris[triBase + f .. + n), f <= 23
+// so that bits 5..7 of a byte shifted left by its bits 0..4 give the child's bits in a 32-bit hit
+// word: one bit per triangle of the node in bits 0..23, one bit per inner slot in bits 24..31.
+struct __attribute__((aligned(16))) Wide8Node {
+    float o[3]; uint32_t expImask;     // ex | ey << 8 | ez << 16 | (mask of inner slots) << 24
+    uint32_t childBase, triBase, meta[2];
+    uint32_t lo[3][2];                 // byte k&3 of lo[a][k>>2] = lower plane of slot k on axis a
+    uint32_t hi[3][2];
+};
+static_assert(sizeof(Wide8Node) == 80, "eight-wide node must be five 16-byte pieces");
+constexpr int32_t kNoRoot = (int32_t)0x80000000;   // root reference of a model with nothing to walk; not a valid child reference
+
 struct __attribute__((aligned(16))) PackedTri {
     float a[3];  int32_t material;   // vertex A,   scene-wide material index
     float ab[3]; int32_t model;      // B - A,      model slot | flags (kTriAlphaTest)
@@ -74,6 +90,7 @@ struct SceneView {
     const float *objects, *materials, *modelInfo, *models, *textures;
     const PackedNode *nodes;
     const WideNode *wnodes;     // four-wide tree, null unless that mode is on
+    const Wide8Node *w8nodes;   // eight-wide tree, null unless that mode is on
     const PackedTri *tris;
     const PackedShade *shade;   // [triangle], same index as tris
     const PackedTri *wtris;     // four-wide trees: the triangles in THEIR leaf order; `ident` holds the index into tris

@@ -52,6 +52,7 @@ using namespace rtd;
 #include "rt_wavefront.h"
 #include "rt_kernels_frame.h"
 #include "rt_kernels_trace.h"
+#include "rt_kernels_trace8.h"
 #include "rt_kernels_shade.h"
 
 // ============================================================================================
@@ -80,11 +81,13 @@ struct rt_ctx {
     bool committed = false;
     PackedNode *dNodes = nullptr;
     WideNode *dWNodes = nullptr;    // four-wide tree (wideBvh only)
-    int wideBvh = 3;                // asked for: 0 off, 1 derived from the uploaded trees, 2 the library's own trees, 3 = 2 + ties re-traced in reference order
+    Wide8Node *dW8Nodes = nullptr;  // eight-wide tree (wideBvh 4)
+    int wideBvh = 3;                // asked for: 0 off, 1 derived from the uploaded trees, 2 the library's own trees, 3 = 2 + ties re-traced in reference order, 4 = 3 on eight-wide trees
     bool wideChosen = false;        // by option or environment: then a scene the four-wide build declines is an error
     int wideNow = 0;                // in effect for the committed scene (0 when the default was declined for it)
     PackedTri *dWTris = nullptr;    // triangles in wide-tree leaf order
-    int wideStackNeed = 0;          // most stack entries a ray can hold in the four-wide tree
+    int wideStackNeed = 0;          // most stack entries a ray can hold in the wide tree
+    uint32_t overflowWords = 0;     // 4-byte words per lane allocated in pb.overflow
     PackedTri *dTris = nullptr;
     PackedShade *dShade = nullptr;
     ModelDesc *dModelDesc = nullptr;
@@ -123,6 +126,27 @@ struct rt_ctx {
     void *comm = nullptr;
     int commRank = 0, commWorld = 1;
     unsigned long long *dFrameCount = nullptr;
+
+    // Frame pipeline.  A render call of few paths (one progressive frame of a viewer) cannot fill the
+    // chip: every kernel of its chain lasts as long as one ray batch's lifetime.  Such calls are queued
+    // on kPipes streams in turn, each with path buffers of its own, so that consecutive calls overlap.
+    // Everything that touches the sum buffer is chained through `accumFence` (the event recorded after
+    // the latest such operation, on whichever stream ran it), so the buffer still receives the frames
+    // in call order and holds the same bits.  Pipe 0 is (stream, pb, P) above.
+    struct Pipe {
+        hipStream_t stream = nullptr;
+        PathBuffers pb{};
+        uint32_t P = 0;
+        uint32_t overflowWords = 0;
+        hipEvent_t fence = nullptr;
+    };
+    static constexpr int kPipes = 3;
+    Pipe pipes[kPipes - 1];
+    hipEvent_t fence = nullptr;        // pipe 0's
+    hipEvent_t accumFence = nullptr;   // null: nothing pending on the sum buffer
+    int nextPipe = 0;
+    bool pipelineOn = true;            // RT_OPT_PIPELINE / env RT_PIPELINE
+    uint64_t pipelinePaths = 4u << 20; // calls of at most this many paths are pipelined
 
     std::vector<std::pair<hipEvent_t, hipEvent_t>> traceEvents, renderEvents;
     std::vector<hipEvent_t> eventPool;
@@ -177,6 +201,43 @@ void drainEvents(rt_ctx *ctx) {
     fold(ctx->renderEvents, ctx->totalMs);
 }
 
+// The stream now queueing work waits (on the device) for the latest operation on the sum buffer.
+void accumWait(rt_ctx *ctx) {
+    if (ctx->accumFence != nullptr) hipStreamWaitEvent(ctx->stream, ctx->accumFence, 0);
+}
+// ... and what it has queued since becomes the latest operation.
+void accumMark(rt_ctx *ctx) {
+    if (ctx->fence == nullptr && hipEventCreateWithFlags(&ctx->fence, hipEventDisableTiming) != hipSuccess) ctx->fence = nullptr;
+    if (ctx->fence != nullptr && hipEventRecord(ctx->fence, ctx->stream) == hipSuccess) ctx->accumFence = ctx->fence;
+    else hipStreamSynchronize(ctx->stream);   // no event to be had: the host waits instead
+}
+// Host-side wait for every stream of the context.
+hipError_t syncAllStreams(rt_ctx *ctx) {
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    for (rt_ctx::Pipe &p : ctx->pipes)
+        if (p.stream != nullptr) {
+            const hipError_t ep = hipStreamSynchronize(p.stream);
+            if (e == hipSuccess) e = ep;
+        }
+    if (e == hipSuccess) ctx->accumFence = nullptr;
+    return e;
+}
+// Makes pipe k (1..kPipes-1) the context's current stream and path buffers for the scope's lifetime.
+struct PipeScope {
+    rt_ctx *ctx;
+    rt_ctx::Pipe *pipe;
+    PipeScope(rt_ctx *c, int k) : ctx(c), pipe(k > 0 ? &c->pipes[k - 1] : nullptr) { swapIn(); }
+    ~PipeScope() { swapIn(); }
+    void swapIn() {
+        if (pipe == nullptr) return;
+        std::swap(ctx->stream, pipe->stream);
+        std::swap(ctx->pb, pipe->pb);
+        std::swap(ctx->P, pipe->P);
+        std::swap(ctx->overflowWords, pipe->overflowWords);
+        std::swap(ctx->fence, pipe->fence);
+    }
+};
+
 // Keeps the number of outstanding timing events bounded for callers that render many times
 // without ever synchronising: folds the pairs that have already completed and, if too many are
 // still pending, waits for the stream.
@@ -196,7 +257,7 @@ void boundEvents(rt_ctx *ctx) {
     };
     reap(ctx->traceEvents, ctx->traceMs);
     reap(ctx->renderEvents, ctx->totalMs);
-    if (ctx->traceEvents.size() + ctx->renderEvents.size() >= kSyncAt && hipStreamSynchronize(ctx->stream) == hipSuccess) drainEvents(ctx);
+    if (ctx->traceEvents.size() + ctx->renderEvents.size() >= kSyncAt && syncAllStreams(ctx) == hipSuccess) drainEvents(ctx);
 }
 
 int gridFor(const rt_ctx *ctx, uint64_t items, int blocksPerCU) {
@@ -682,25 +743,30 @@ bool sahTree(const std::vector<float> &mdl, const ModelDesc &d, const std::vecto
     return true;
 }
 
-// Four-wide tree of every model, collapsed from the binary tree of the model stream: a node adopts
-// the children of its child with the largest box until it has four (or only leaves are left).
-// `descs` must have passed repackScene; wideRootRef receives the new tree's root.
-int buildWideNodes(rt_ctx *ctx, std::vector<ModelDesc> &descs, std::vector<WideNode> &wnodes, const std::vector<PackedTri> &tris, std::vector<PackedTri> &wtris) {
+// Binary trees of all models in one array, as the collapse into wide nodes reads them: box, children
+// (indices into the array), or the leaf reference.
+struct BinNode { float box[6]; int32_t left, right; int32_t leafRef; bool leaf; };
+struct BinaryTrees {
+    std::vector<BinNode> bin;
+    std::vector<std::pair<int32_t, ModelDesc *>> roots;   // root node and model of every tree that is more than one leaf
+    double reach = 0.0;                                    // largest coordinate magnitude of any root box
+};
+
+// Fills `trees` with every model's binary tree: the library's own binned-SAH tree when `rebuild` (then
+// `wtris` receives the triangle records in that tree's leaf order), else the uploaded one.  A model
+// whose tree is a single leaf gets that leaf's reference in wideRootRef and no entry in `roots`.
+int binaryTreesOfModels(rt_ctx *ctx, std::vector<ModelDesc> &descs, const std::vector<PackedTri> &tris, std::vector<PackedTri> &wtris, bool rebuild, BinaryTrees &trees) {
     const std::vector<float> &mdl = ctx->host[RT_SLOT_MODELS];
-    ctx->wideStackNeed = 0;
-    const bool rebuild = ctx->wideBvh >= 2;
+    std::vector<BinNode> &bin = trees.bin;
+    auto &roots = trees.roots;
+    double &reach = trees.reach;
     // Triangles in the order of the trees walked, each naming its index in `tris` (what hit records
     // and shading use): the uploaded order unless a model's tree is rebuilt below.
     auto mark = std::chrono::steady_clock::now();
     wtris = tris;
     for (size_t i = 0; i < wtris.size(); ++i) wtris[i].ident = (int32_t)i;
     commitLap("triangle copy", mark);
-
-    // All binary nodes in one array: box, children (indices into it), or the leaf reference.
-    struct Bin { float box[6]; int32_t left, right; int32_t leafRef; bool leaf; };
-    std::vector<Bin> bin;
-    std::vector<std::pair<int32_t, ModelDesc *>> roots;
-    double reach = 0.0;
+    using Bin = BinNode;
     for (ModelDesc &d : descs) {
         d.wideRootRef = d.rootRef;   // a tree that is one leaf: same reference, wtris being a copy of tris there
         if (d.nodesCount <= 0) continue;
@@ -747,6 +813,21 @@ int buildWideNodes(rt_ctx *ctx, std::vector<ModelDesc> &descs, std::vector<WideN
         for (int k = 0; k < 6; ++k) reach = std::max(reach, (double)std::fabs(bin[(size_t)base].box[k]));
     }
     commitLap("binary trees, all models", mark);
+    return RT_OK;
+}
+
+// Four-wide tree of every model, collapsed from the binary tree of the model stream: a node adopts
+// the children of its child with the largest box until it has four (or only leaves are left).
+// `descs` must have passed repackScene; wideRootRef receives the new tree's root.
+int buildWideNodes(rt_ctx *ctx, std::vector<ModelDesc> &descs, std::vector<WideNode> &wnodes, const std::vector<PackedTri> &tris, std::vector<PackedTri> &wtris) {
+    ctx->wideStackNeed = 0;
+    BinaryTrees trees;
+    const int treesRc = binaryTreesOfModels(ctx, descs, tris, wtris, ctx->wideBvh >= 2, trees);
+    if (treesRc != RT_OK) return treesRc;
+    std::vector<BinNode> &bin = trees.bin;
+    auto &roots = trees.roots;
+    const double reach = trees.reach;
+    auto mark = std::chrono::steady_clock::now();
     if (roots.empty()) return RT_OK;
     if (!(reach <= 1e15)) return RT_ERR_SCENE;   // also catches NaN
     // Margin around every box for the rounding of the plane arithmetic on the device, whose operands
@@ -885,6 +966,222 @@ int buildWideNodes(rt_ctx *ctx, std::vector<ModelDesc> &descs, std::vector<WideN
     return RT_OK;
 }
 
+// Eight-wide tree of every model (RT_OPT_WIDE_BVH 4), collapsed from the library's binary trees: a
+// node adopts the children of its child with the largest box until it has eight.  Layout and child
+// encoding: Wide8Node in rt_device.h.  The inner children of a node get consecutive node numbers and
+// the triangles of its leaf children consecutive places in `w8tris`, both in slot order; slots are
+// dealt so that a child lying towards (+x, +y, +z) of the node's centre sits in the slot whose number
+// has those bits set, which lets the device visit children front to back by slot number alone.
+int buildWide8(rt_ctx *ctx, std::vector<ModelDesc> &descs, std::vector<Wide8Node> &w8, const std::vector<PackedTri> &tris, std::vector<PackedTri> &w8tris) {
+    ctx->wideStackNeed = 0;
+    BinaryTrees trees;
+    std::vector<PackedTri> leafTris;   // in the binary trees' leaf order
+    const int treesRc = binaryTreesOfModels(ctx, descs, tris, leafTris, true, trees);
+    if (treesRc != RT_OK) return treesRc;
+    const std::vector<BinNode> &bin = trees.bin;
+    auto mark = std::chrono::steady_clock::now();
+    if (!(trees.reach <= 1e15)) return RT_ERR_SCENE;   // also catches NaN
+    const double pad = std::ldexp(trees.reach, -21);   // see buildWideNodes
+
+    w8tris.clear();
+    w8tris.reserve(tris.size());
+    auto leafFirst = [&](int32_t n) { return (~(uint32_t)bin[(size_t)n].leafRef) >> 2; };
+    auto leafCount = [&](int32_t n) { return (int)((~(uint32_t)bin[(size_t)n].leafRef) & 3u); };
+    // Appends the triangles of a leaf reference (into leafTris) and returns the reference into w8tris.
+    auto moveLeaf = [&](int32_t ref) -> int32_t {
+        const uint32_t code = ~(uint32_t)ref, first = code >> 2, count = code & 3u;
+        const uint32_t at = (uint32_t)w8tris.size();
+        for (uint32_t k = 0; k < count; ++k) w8tris.push_back(leafTris[(size_t)first + k]);
+        return ~(int32_t)((at << 2) | count);
+    };
+    // Models whose tree is one leaf keep a leaf reference as their root; a leaf without triangles
+    // (and a model without triangles) has nothing to walk.
+    for (ModelDesc &d : descs) {
+        if (d.nodesCount <= 0) continue;
+        bool hasTree = false;
+        for (const auto &r : trees.roots) hasTree = hasTree || r.second == &d;
+        if (hasTree) continue;
+        const uint32_t count = (~(uint32_t)d.wideRootRef) & 3u;
+        d.wideRootRef = (d.wideRootRef < 0 && count > 0) ? moveLeaf(d.wideRootRef) : kNoRoot;
+    }
+    auto area = [&](int32_t n) {
+        const float *b = bin[(size_t)n].box;
+        const double ex = (double)b[3] - b[0], ey = (double)b[4] - b[1], ez = (double)b[5] - b[2];
+        return ex * ey + ey * ez + ez * ex;
+    };
+    struct Family { int32_t kids[8]; };   // binary node standing behind each slot, -1 = empty
+    std::vector<Family> families;
+    struct Item { int32_t node; uint32_t wide; int depth; };
+    std::vector<Item> todo;
+    auto newNode = [&]() -> uint32_t {
+        w8.emplace_back();
+        families.push_back(Family{{-1, -1, -1, -1, -1, -1, -1, -1}});
+        return (uint32_t)(w8.size() - 1);
+    };
+    for (auto &rootOf : trees.roots) {
+        const uint32_t root = newNode();
+        rootOf.second->wideRootRef = (int32_t)root;
+        todo.push_back({rootOf.first, root, 0});
+    }
+    while (!todo.empty()) {
+        const Item it = todo.back();
+        todo.pop_back();
+        ctx->wideStackNeed = std::max(ctx->wideStackNeed, it.depth);   // one stack entry per ancestor at most
+        int32_t kids[8] = {bin[(size_t)it.node].left, bin[(size_t)it.node].right, -1, -1, -1, -1, -1, -1};
+        int nk = 2;
+        while (nk < 8) {
+            int best = -1;
+            double bestArea = -1.0;
+            for (int i = 0; i < nk; ++i) {
+                if (bin[(size_t)kids[i]].leaf) continue;
+                const double a = area(kids[i]);
+                if (best < 0 || a > bestArea) { best = i; bestArea = a; }
+            }
+            if (best < 0) break;
+            const int32_t n = kids[best];
+            kids[best] = bin[(size_t)n].left;
+            kids[nk++] = bin[(size_t)n].right;
+        }
+        int kept = 0;
+        for (int i = 0; i < nk; ++i)
+            if (!(bin[(size_t)kids[i]].leaf && leafCount(kids[i]) == 0)) kids[kept++] = kids[i];
+        nk = kept;
+        // Slots: greedily the (child, slot) pair with the largest projection of the child's centre
+        // (relative to the centre of all children) on the slot's diagonal, until every child sits.
+        double centre[3] = {0.0, 0.0, 0.0}, lo[3], hi[3];
+        for (int a = 0; a < 3; ++a) { lo[a] = INFINITY; hi[a] = -INFINITY; }
+        for (int i = 0; i < nk; ++i)
+            for (int a = 0; a < 3; ++a) {
+                lo[a] = std::min(lo[a], (double)bin[(size_t)kids[i]].box[a]);
+                hi[a] = std::max(hi[a], (double)bin[(size_t)kids[i]].box[3 + a]);
+            }
+        for (int a = 0; a < 3; ++a) centre[a] = 0.5 * (lo[a] + hi[a]);
+        double cost[8][8];
+        for (int i = 0; i < nk; ++i) {
+            double rel[3];
+            for (int a = 0; a < 3; ++a) rel[a] = 0.5 * ((double)bin[(size_t)kids[i]].box[a] + (double)bin[(size_t)kids[i]].box[3 + a]) - centre[a];
+            for (int sl = 0; sl < 8; ++sl) cost[i][sl] = ((sl & 1) ? rel[0] : -rel[0]) + ((sl & 2) ? rel[1] : -rel[1]) + ((sl & 4) ? rel[2] : -rel[2]);
+        }
+        Family fam{{-1, -1, -1, -1, -1, -1, -1, -1}};
+        bool seated[8] = {false, false, false, false, false, false, false, false};
+        for (int round = 0; round < nk; ++round) {
+            int bi = -1, bs = -1;
+            for (int i = 0; i < nk; ++i) {
+                if (seated[i]) continue;
+                for (int sl = 0; sl < 8; ++sl)
+                    if (fam.kids[sl] < 0 && (bi < 0 || cost[i][sl] > cost[bi][bs])) { bi = i; bs = sl; }
+            }
+            seated[bi] = true;
+            fam.kids[bs] = kids[bi];
+        }
+        Wide8Node wn{};
+        uint32_t imask = 0, innerCount = 0, triCount = 0;
+        uint8_t meta[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const uint32_t triBase = (uint32_t)w8tris.size();
+        for (int sl = 0; sl < 8; ++sl) {
+            const int32_t kid = fam.kids[sl];
+            if (kid < 0) continue;
+            if (bin[(size_t)kid].leaf) {
+                const int count = leafCount(kid);
+                meta[sl] = (uint8_t)((((1u << count) - 1u) << 5) | triCount);
+                for (int k = 0; k < count; ++k) w8tris.push_back(leafTris[(size_t)leafFirst(kid) + (size_t)k]);
+                triCount += (uint32_t)count;
+            } else {
+                meta[sl] = (uint8_t)(0x38u + (uint32_t)sl);   // one bit, at place 24 + slot
+                imask |= 1u << sl;
+                innerCount++;
+            }
+        }
+        wn.childBase = (uint32_t)w8.size();
+        wn.triBase = triBase;
+        wn.meta[0] = (uint32_t)meta[0] | ((uint32_t)meta[1] << 8) | ((uint32_t)meta[2] << 16) | ((uint32_t)meta[3] << 24);
+        wn.meta[1] = (uint32_t)meta[4] | ((uint32_t)meta[5] << 8) | ((uint32_t)meta[6] << 16) | ((uint32_t)meta[7] << 24);
+        wn.expImask = imask << 24;
+        // inner children: consecutive numbers in slot order; expanded in that order too (depth first)
+        std::vector<Item> mine;
+        for (int sl = 0; sl < 8; ++sl) {
+            const int32_t kid = fam.kids[sl];
+            if (kid < 0 || bin[(size_t)kid].leaf) continue;
+            const uint32_t child = newNode();
+            mine.push_back({kid, child, it.depth + 1});
+        }
+        for (size_t k = mine.size(); k-- > 0;) todo.push_back(mine[k]);
+        w8[(size_t)it.wide] = wn;
+        families[(size_t)it.wide] = fam;
+    }
+    commitLap("eight-wide structure", mark);
+
+    // Child boxes as 8-bit plane numbers on a power-of-two grid per axis, rounded outwards.
+    std::atomic<bool> bad{false};
+    auto quantise = [&](size_t first, size_t last) {
+        for (size_t w = first; w < last; ++w) {
+            const int32_t *kids = families[w].kids;
+            Wide8Node &wn = w8[w];
+            for (int a = 0; a < 3; ++a) {
+                double lower = 0.0, upper = 0.0;
+                bool any = false;
+                for (int i = 0; i < 8; ++i) {
+                    if (kids[i] < 0) continue;
+                    const double mn = bin[(size_t)kids[i]].box[a], mx = bin[(size_t)kids[i]].box[3 + a];
+                    if (!(std::fabs(mn) <= 1e15) || !(std::fabs(mx) <= 1e15) || mn > mx) { bad = true; return; }
+                    if (!any || mn < lower) lower = mn;
+                    if (!any || mx > upper) upper = mx;
+                    any = true;
+                }
+                float o = (float)(lower - pad);
+                if ((double)o > lower - pad) o = std::nextafterf(o, -INFINITY);
+                const double extent = (upper + pad) - (double)o;
+                int e = -60;
+                if (extent > 0.0) e = std::max(-60, (int)std::ceil(std::log2(extent / 255.0)));
+                for (;; ++e) {
+                    const double step = std::ldexp(1.0, e);
+                    bool fits = true;
+                    uint32_t wlo[2] = {0, 0}, whi[2] = {0, 0};
+                    for (int i = 0; i < 8 && fits; ++i) {
+                        uint32_t qlo = 255, qhi = 0;   // unused slot: inverted
+                        if (kids[i] >= 0) {
+                            const double mn = (double)bin[(size_t)kids[i]].box[a] - pad, mx = (double)bin[(size_t)kids[i]].box[3 + a] + pad;
+                            long ql = (long)std::floor((mn - (double)o) / step), qh = (long)std::ceil((mx - (double)o) / step);
+                            ql = std::max(0l, std::min(ql, 255l));
+                            while (ql > 0 && (double)o + (double)ql * step > mn) --ql;
+                            qh = std::max(qh, 0l);
+                            while (qh <= 255 && (double)o + (double)qh * step < mx) ++qh;
+                            if (qh > 255) { fits = false; break; }
+                            qlo = (uint32_t)ql;
+                            qhi = (uint32_t)qh;
+                        }
+                        wlo[i >> 2] |= qlo << (8 * (i & 3));
+                        whi[i >> 2] |= qhi << (8 * (i & 3));
+                    }
+                    if (fits) {
+                        if (e + 127 < 1 || e + 127 > 254) { bad = true; return; }
+                        wn.o[a] = o;
+                        wn.expImask |= (uint32_t)(e + 127) << (8 * a);
+                        wn.lo[a][0] = wlo[0]; wn.lo[a][1] = wlo[1];
+                        wn.hi[a][0] = whi[0]; wn.hi[a][1] = whi[1];
+                        break;
+                    }
+                }
+            }
+        }
+    };
+    {
+        const size_t total = w8.size();
+        const int workers = total >= 32768 ? buildThreads() : 1;
+        ThreadGroup pool((size_t)workers);
+        for (int t = 1; t < workers; ++t) {
+            const size_t first = total * (size_t)t / (size_t)workers, last = total * (size_t)(t + 1) / (size_t)workers;
+            if (!pool.spawn(quantise, first, last)) quantise(first, last);
+        }
+        quantise(0, total / (size_t)workers);
+        pool.join();
+    }
+    if (bad) return RT_ERR_SCENE;
+    if (w8tris.size() >= (1u << 29) || w8.size() >= (1u << 30)) return RT_ERR_SCENE;
+    commitLap("child boxes to 8 bits", mark);
+    return RT_OK;
+}
+
 // (Re)allocates every per-path buffer for `want` paths.  ctx->P is zero while the set is incomplete,
 // so a failed attempt can never leave a capacity that some buffer does not have.
 int allocPathBuffers(rt_ctx *ctx, uint64_t want64) {
@@ -969,7 +1266,12 @@ void launchTrace(rt_ctx *ctx, int extParity, int stage, uint64_t maxRays) {
     const bool prims = ctx->objectCount > 0;
     TraceFn fn;
     int wavesPerSimd;
-    if (ctx->wideNow) {
+    if (ctx->wideNow == 4) {
+        static const TraceFn wide8Variants[2][2][2] = {{{k_trace8<false, false, false>, k_trace8<false, false, true>}, {k_trace8<false, true, false>, k_trace8<false, true, true>}},
+                                                       {{k_trace8<true, false, false>, k_trace8<true, false, true>}, {k_trace8<true, true, false>, k_trace8<true, true, true>}}};
+        fn = wide8Variants[ctx->countersOn ? 1 : 0][prims ? 1 : 0][ctx->modelsCount > 2 ? 1 : 0];
+        wavesPerSimd = RT_W8;
+    } else if (ctx->wideNow) {
         fn = wideVariants[ctx->countersOn ? 1 : 0][ctx->modelsCount > 2 ? 1 : 0][ctx->hasAlphaTest ? 1 : 0][prims ? 1 : 0];
         wavesPerSimd = ctx->hasAlphaTest ? RT_WWIDE_ALPHA : RT_WWIDE;
     } else {
@@ -988,7 +1290,7 @@ void launchTrace(rt_ctx *ctx, int extParity, int stage, uint64_t maxRays) {
     constexpr int handsPerWave = 6;   // 64-ray hands a wave should get to deal with (swept 2..12: 3 -> -4 %, 12 -> -8 %)
     const uint64_t fewRaysGrid = std::max<uint64_t>(maxRays / (64 * handsPerWave * (kBlock / 64)), (uint64_t)ctx->numCUs);
     const int grid = (int)std::min<uint64_t>((uint64_t)fullGrid, fewRaysGrid);
-    const bool exactTies = ctx->wideNow == 3;
+    const bool exactTies = ctx->wideNow >= 3;
     PathBuffers pb = ctx->pb;
     if (!exactTies) pb.retrace = nullptr;
     hipLaunchKernelGGL(fn, dim3(grid), dim3(kBlock), 0, ctx->stream, ctx->view, pb, extParity, stage, refill, ctx->innerShare);
@@ -1035,8 +1337,10 @@ int runBatch(rt_ctx *ctx, const Batch &bt) {
     }
 
     const int gRes = gridFor(ctx, fp.npt, 16);
+    accumWait(ctx);   // frames reach the sum buffer in call order, whichever stream traced them
     if (spectral) hipLaunchKernelGGL(k_resolve<true>, dim3(gRes), dim3(kBlock), 0, ctx->stream, fp, bt, ctx->pb, ctx->dAccum, ctx->dPartial);
     else hipLaunchKernelGGL(k_resolve<false>, dim3(gRes), dim3(kBlock), 0, ctx->stream, fp, bt, ctx->pb, ctx->dAccum, ctx->dPartial);
+    accumMark(ctx);
     RT_HIP(hipGetLastError());
     return RT_OK;
 }
@@ -1151,6 +1455,7 @@ int rt_reduce(rt_ctx *ctx, int root) {
     ncclComm_t comm = static_cast<ncclComm_t>(ctx->comm);
     const size_t floats = (size_t)ctx->W * ctx->H * 4;
     unsigned long long frames = ctx->framesAccum;
+    accumWait(ctx);
     RT_HIP(hipMemcpyAsync(ctx->dFrameCount, &frames, sizeof frames, hipMemcpyHostToDevice, ctx->stream));
     // Both collectives are queued on the context's stream, behind the render work already there.
     RT_NCCL(ctx, api, api->reduce(ctx->dAccum, ctx->dAccum, floats, ncclFloat, ncclSum, root, comm, ctx->stream));
@@ -1193,8 +1498,9 @@ int rt_create(rt_ctx **out, int device) {
         if (v > 0) ctx->maxPaths = (uint32_t)std::min<long>(v, 1l << 30);
     }
     if (const char *env = std::getenv("RT_TILE_MAJOR")) ctx->planesInner = std::atoi(env) != 0;
+    if (const char *env = std::getenv("RT_PIPELINE")) ctx->pipelineOn = std::atoi(env) != 0;
     if (const char *env = std::getenv("RT_WIDE_BVH")) {
-        ctx->wideBvh = std::min(std::max(std::atoi(env), 0), 3);
+        ctx->wideBvh = std::min(std::max(std::atoi(env), 0), 4);
         ctx->wideChosen = true;
     }
     if (const char *env = std::getenv("RT_INNER_SHARE")) {
@@ -1212,9 +1518,17 @@ int rt_create(rt_ctx **out, int device) {
 void rt_destroy(rt_ctx *ctx) {
     if (ctx == nullptr) return;
     hipSetDevice(ctx->device);
-    hipStreamSynchronize(ctx->stream);
+    syncAllStreams(ctx);
+    for (rt_ctx::Pipe &pipe : ctx->pipes) {
+        void *mine[] = {pipe.pb.rays, pipe.pb.hits, pipe.pb.stA, pipe.pb.stB, pipe.pb.neeA, pipe.pb.neeB, pipe.pb.neeC, pipe.pb.qExt[0], pipe.pb.qExt[1],
+                        pipe.pb.qShadow, pipe.pb.stages, pipe.pb.retrace, pipe.pb.overflow};   // the counters belong to pipe 0
+        for (void *p : mine) if (p) hipFree(p);
+        if (pipe.stream) hipStreamDestroy(pipe.stream);
+        if (pipe.fence) hipEventDestroy(pipe.fence);
+    }
+    if (ctx->fence) hipEventDestroy(ctx->fence);
     for (float *p : ctx->dStream) if (p) hipFree(p);
-    void *owned[] = {ctx->dNodes, ctx->dWNodes, ctx->pb.overflow, ctx->pb.retrace, ctx->dWTris, ctx->dTris, ctx->dShade, ctx->dModelDesc, ctx->accumExternal ? nullptr : (void *)ctx->dAccum, ctx->dPartial,
+    void *owned[] = {ctx->dNodes, ctx->dWNodes, ctx->dW8Nodes, ctx->pb.overflow, ctx->pb.retrace, ctx->dWTris, ctx->dTris, ctx->dShade, ctx->dModelDesc, ctx->accumExternal ? nullptr : (void *)ctx->dAccum, ctx->dPartial,
                      ctx->pb.rays, ctx->pb.hits, ctx->pb.stA, ctx->pb.stB, ctx->pb.neeA, ctx->pb.neeB, ctx->pb.neeC,
                      ctx->pb.qExt[0], ctx->pb.qExt[1], ctx->pb.qShadow, ctx->pb.stages, ctx->pb.counters};
     for (void *p : owned) if (p) hipFree(p);
@@ -1246,7 +1560,7 @@ static int commitScene(rt_ctx *ctx, int objectCount, int modelsCount, int lightS
         lightSourcesCount == ctx->lightSourcesCount)
         return RT_OK;
     RT_HIP(hipSetDevice(ctx->device));
-    RT_HIP(hipStreamSynchronize(ctx->stream));
+    RT_HIP(syncAllStreams(ctx));
     ctx->committed = false;   // a failed commit leaves the context without a scene, never with a stale one
     ctx->objectCount = objectCount;
     ctx->modelsCount = modelsCount;
@@ -1280,29 +1594,42 @@ static int commitScene(rt_ctx *ctx, int objectCount, int modelsCount, int lightS
     }
     lap("stream upload", mark);
     std::vector<WideNode> wnodes;
+    std::vector<Wide8Node> w8nodes;
     std::vector<PackedTri> wtris;
     ctx->wideNow = tris.empty() ? 0 : ctx->wideBvh;   // nothing to build over analytic primitives alone
+    // The eight-wide kernel has no alpha-cut phase: scenes with alpha-cut textures walk the four-wide trees.
+    if (ctx->wideNow == 4 && ctx->hasAlphaTest) ctx->wideNow = 3;
     if (ctx->wideNow) {
-        rc = buildWideNodes(ctx, descs, wnodes, tris, wtris);
-        // A scene the four-wide build cannot take (coordinates beyond its box arithmetic, NaN) is
+        rc = ctx->wideNow == 4 ? buildWide8(ctx, descs, w8nodes, tris, wtris) : buildWideNodes(ctx, descs, wnodes, tris, wtris);
+        // A scene the wide build cannot take (coordinates beyond its box arithmetic, NaN) is
         // walked in the reference's order, as it would be with the option off, unless the caller
-        // asked for the four-wide trees by name.
+        // asked for the wide trees by name.
         if (rc == RT_ERR_SCENE && !ctx->wideChosen) ctx->wideNow = 0;
         else if (rc != RT_OK) return rc;
     }
-    lap("four-wide trees", mark);
+    lap("wide trees", mark);
     if (ctx->wideNow) {
         if ((rc = devAlloc(ctx, &ctx->dWTris, wtris.size())) != RT_OK) return rc;
         if (!wtris.empty()) RT_HIP(hipMemcpy(ctx->dWTris, wtris.data(), wtris.size() * sizeof(PackedTri), hipMemcpyHostToDevice));
         if ((rc = devAlloc(ctx, &ctx->dWNodes, wnodes.size())) != RT_OK) return rc;
         if (!wnodes.empty()) RT_HIP(hipMemcpy(ctx->dWNodes, wnodes.data(), wnodes.size() * sizeof(WideNode), hipMemcpyHostToDevice));
-        // Stack entries that do not fit in LDS: one column per lane of every wave the grid can hold.
-        const int deeper = std::max(0, ctx->wideStackNeed - kWideStack);
-        if ((uint32_t)deeper > ctx->pb.overflowDepth || ctx->pb.overflow == nullptr) {
-            const size_t waves = (size_t)ctx->numCUs * std::max(RT_WWIDE, RT_WWIDE_ALPHA) * (kBlock / 64);
-            if ((rc = devAlloc(ctx, &ctx->pb.overflow, waves * (size_t)std::max(deeper, 1) * 64)) != RT_OK) return rc;
-            ctx->pb.overflowDepth = (uint32_t)std::max(deeper, 1);
+        if ((rc = devAlloc(ctx, &ctx->dW8Nodes, w8nodes.size())) != RT_OK) return rc;
+        if (!w8nodes.empty()) RT_HIP(hipMemcpy(ctx->dW8Nodes, w8nodes.data(), w8nodes.size() * sizeof(Wide8Node), hipMemcpyHostToDevice));
+        // Stack entries that do not fit in LDS: one column per lane of every wave the grid can hold
+        // (4-byte entries beyond kWideStack for the four-wide walk, 8-byte entries beyond kWide8Stack for the eight-wide).
+        const bool eight = ctx->wideNow == 4;
+        // RT_W8_LDS_STACK (1..kWide8Stack) keeps fewer entries on chip: a testing aid for the in-memory part.
+        int onChip8 = kWide8Stack;
+        if (const char *env = std::getenv("RT_W8_LDS_STACK")) onChip8 = std::min(std::max(std::atoi(env), 1), kWide8Stack);
+        ctx->pb.overflowFrom = (uint32_t)onChip8;
+        const int deeper = std::max(1, ctx->wideStackNeed - (eight ? onChip8 : kWideStack));
+        const uint32_t words = (uint32_t)deeper * (eight ? 2u : 1u);
+        if (words > ctx->overflowWords || ctx->pb.overflow == nullptr) {
+            const size_t waves = (size_t)ctx->numCUs * std::max(std::max(RT_WWIDE, RT_WWIDE_ALPHA), RT_W8) * (kBlock / 64);
+            if ((rc = devAlloc(ctx, &ctx->pb.overflow, waves * (size_t)words * 64)) != RT_OK) return rc;
+            ctx->overflowWords = words;
         }
+        ctx->pb.overflowDepth = ctx->overflowWords / (eight ? 2u : 1u);   // entries per lane the kernels may index
     }
     if ((rc = devAlloc(ctx, &ctx->dNodes, nodes.size())) != RT_OK) return rc;
     if ((rc = devAlloc(ctx, &ctx->dTris, tris.size())) != RT_OK) return rc;
@@ -1323,6 +1650,7 @@ static int commitScene(rt_ctx *ctx, int objectCount, int modelsCount, int lightS
     v.textures = ctx->dStream[RT_SLOT_TEXTURES];
     v.nodes = ctx->dNodes;
     v.wnodes = ctx->wideNow ? ctx->dWNodes : nullptr;
+    v.w8nodes = ctx->wideNow == 4 ? ctx->dW8Nodes : nullptr;
     v.wtris = ctx->wideNow ? ctx->dWTris : nullptr;
     v.tris = ctx->dTris;
     v.shade = ctx->dShade;
@@ -1338,7 +1666,7 @@ static int commitScene(rt_ctx *ctx, int objectCount, int modelsCount, int lightS
 int rt_resize(rt_ctx *ctx, int width, int height) {
     if (ctx == nullptr || width <= 0 || height <= 0 || (uint64_t)width * height > (1u << 28)) return RT_ERR_INVALID;
     RT_HIP(hipSetDevice(ctx->device));
-    RT_HIP(hipStreamSynchronize(ctx->stream));
+    RT_HIP(syncAllStreams(ctx));
     ctx->W = width;
     ctx->H = height;
     const size_t px = (size_t)width * height;
@@ -1351,6 +1679,7 @@ int rt_resize(rt_ctx *ctx, int width, int height) {
     if ((rc = devAlloc(ctx, &ctx->dPartial, px)) != RT_OK) return rc;
     RT_HIP(hipMemsetAsync(ctx->dAccum, 0, px * sizeof(float4), ctx->stream));
     RT_HIP(hipMemsetAsync(ctx->dPartial, 0, px * sizeof(float4), ctx->stream));
+    accumMark(ctx);
     ctx->framesAccum = 0;
     ctx->frameSet = false;
     return RT_OK;
@@ -1417,8 +1746,36 @@ int rt_render(rt_ctx *ctx, uint32_t first_frame, uint32_t n_frames, uint32_t fra
     const FrameParams &fp = ctx->fp;
     const uint64_t totalPlanes = (uint64_t)n_frames * fp.S;
     if (totalPlanes > 0xffffffffull) return RT_ERR_INVALID;
+    // A call of few paths takes the next stream of the frame pipeline; anything larger fills the chip
+    // by itself and stays on the context's own stream (its resolve pass still waits its turn).
+    int pipeNo = 0;
+    if (ctx->pipelineOn && totalPlanes * fp.npt <= ctx->pipelinePaths) {
+        pipeNo = ctx->nextPipe;
+        ctx->nextPipe = (ctx->nextPipe + 1) % rt_ctx::kPipes;
+        if (pipeNo > 0) {
+            rt_ctx::Pipe &pipe = ctx->pipes[pipeNo - 1];
+            if (ctx->pb.counters == nullptr) {
+                pipeNo = 0;   // the shared counters are created with the first pipe's buffers
+            } else if (pipe.stream == nullptr) {
+                if (hipStreamCreate(&pipe.stream) != hipSuccess) { pipe.stream = nullptr; (void)hipGetLastError(); pipeNo = 0; }
+                else pipe.pb.counters = ctx->pb.counters;
+            }
+        }
+    }
+    PipeScope onPipe(ctx, pipeNo);
     int rc = ensurePathBuffers(ctx, totalPlanes * fp.npt);
     if (rc != RT_OK) return rc;
+    if (pipeNo > 0 && ctx->wideNow) {
+        // this pipe's copy of the part of the traversal stack that does not fit in LDS
+        const rt_ctx::Pipe &first = *onPipe.pipe;   // holds pipe 0's state while the scope lasts
+        if (ctx->pb.overflow == nullptr || ctx->overflowWords < first.overflowWords) {
+            const size_t waves = (size_t)ctx->numCUs * std::max(std::max(RT_WWIDE, RT_WWIDE_ALPHA), RT_W8) * (kBlock / 64);
+            if ((rc = devAlloc(ctx, &ctx->pb.overflow, waves * (size_t)first.overflowWords * 64)) != RT_OK) return rc;
+            ctx->overflowWords = first.overflowWords;
+        }
+        ctx->pb.overflowDepth = first.pb.overflowDepth;
+        ctx->pb.overflowFrom = first.pb.overflowFrom;
+    }
     boundEvents(ctx);
 
     hipEvent_t e0 = takeEvent(ctx), e1 = takeEvent(ctx);
@@ -1457,7 +1814,7 @@ int rt_reserve(rt_ctx *ctx, uint32_t n_frames) {
     RT_HIP(hipSetDevice(ctx->device));
     const uint64_t totalPlanes = (uint64_t)n_frames * ctx->fp.S;
     if (totalPlanes > 0xffffffffull) return RT_ERR_INVALID;
-    RT_HIP(hipStreamSynchronize(ctx->stream));   // the buffers may be in use by queued work
+    RT_HIP(syncAllStreams(ctx));   // the buffers may be in use by queued work
     return ensurePathBuffers(ctx, totalPlanes * ctx->fp.npt);
 }
 
@@ -1465,7 +1822,9 @@ int rt_reset_accum(rt_ctx *ctx) {
     if (ctx == nullptr) return RT_ERR_INVALID;
     if (ctx->dAccum == nullptr) return RT_ERR_STATE;
     RT_HIP(hipSetDevice(ctx->device));
+    accumWait(ctx);
     RT_HIP(hipMemsetAsync(ctx->dAccum, 0, (size_t)ctx->W * ctx->H * sizeof(float4), ctx->stream));
+    accumMark(ctx);
     ctx->framesAccum = 0;
     return RT_OK;
 }
@@ -1473,7 +1832,7 @@ int rt_reset_accum(rt_ctx *ctx) {
 int rt_sync(rt_ctx *ctx) {
     if (ctx == nullptr) return RT_ERR_INVALID;
     RT_HIP(hipSetDevice(ctx->device));
-    RT_HIP(hipStreamSynchronize(ctx->stream));
+    RT_HIP(syncAllStreams(ctx));
     drainEvents(ctx);
     return RT_OK;
 }
@@ -1497,6 +1856,7 @@ int rt_display_rgba8(rt_ctx *ctx, uint8_t *rgba8, size_t bytes) {
     RT_HIP(hipSetDevice(ctx->device));
     uchar4 *dOut = nullptr;
     RT_HIP(hipMalloc(reinterpret_cast<void **>(&dOut), px * sizeof(uchar4)));
+    accumWait(ctx);   // every frame queued so far, on whichever stream
     hipLaunchKernelGGL(k_display, dim3(gridFor(ctx, px, 8)), dim3(kBlock), 0, ctx->stream, ctx->dAccum, dOut, (uint32_t)px);
     hipError_t e = hipMemcpyAsync(rgba8, dOut, bytes, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -1520,6 +1880,7 @@ int rt_display_rgba8_noalloc(rt_ctx *ctx, uint8_t *rgba8, size_t bytes) {
     }
     RT_HIP(hipSetDevice(ctx->device));
     // The kernel writes every pixel of the frame, so what an earlier call left in the staging area does not matter.
+    accumWait(ctx);   // every frame queued so far, on whichever stream
     hipLaunchKernelGGL(k_display, dim3(gridFor(ctx, px, 8)), dim3(kBlock), 0, ctx->stream, ctx->dAccum, ctx->displayScratch, (uint32_t)px);
     RT_HIP(hipMemcpyAsync(rgba8, ctx->displayScratch, bytes, hipMemcpyDefault, ctx->stream));
     RT_HIP(hipStreamSynchronize(ctx->stream));
@@ -1531,7 +1892,7 @@ int rt_restore_accum(rt_ctx *ctx, const float *rgba_sum, size_t floats, uint32_t
     if (ctx->dAccum == nullptr) return RT_ERR_STATE;
     if (floats != (size_t)ctx->W * ctx->H * 4) return RT_ERR_INVALID;
     RT_HIP(hipSetDevice(ctx->device));
-    RT_HIP(hipStreamSynchronize(ctx->stream));
+    RT_HIP(syncAllStreams(ctx));
     RT_HIP(hipMemcpy(ctx->dAccum, rgba_sum, floats * sizeof(float), hipMemcpyHostToDevice));
     ctx->framesAccum = frames;
     return RT_OK;
@@ -1550,7 +1911,7 @@ int rt_bind_accum(rt_ctx *ctx, void *dev_ptr, size_t floats) {
     if (ctx->W <= 0) return RT_ERR_STATE;
     if (floats != (size_t)ctx->W * ctx->H * 4 || (reinterpret_cast<uintptr_t>(dev_ptr) & 15u) != 0) return RT_ERR_INVALID;
     RT_HIP(hipSetDevice(ctx->device));
-    RT_HIP(hipStreamSynchronize(ctx->stream));
+    RT_HIP(syncAllStreams(ctx));
     if (!ctx->accumExternal && ctx->dAccum != nullptr) RT_HIP(hipFree(ctx->dAccum));
     ctx->dAccum = static_cast<float4 *>(dev_ptr);
     ctx->accumExternal = true;
@@ -1722,8 +2083,11 @@ int rt_set_option(rt_ctx *ctx, int option, int value) {
             if (value < 1) return RT_ERR_INVALID;
             ctx->maxPaths = (uint32_t)value;
             return RT_OK;
+        case RT_OPT_PIPELINE:
+            ctx->pipelineOn = value != 0;
+            return RT_OK;
         case RT_OPT_WIDE_BVH:
-            if (value < 0 || value > 3) return RT_ERR_INVALID;
+            if (value < 0 || value > 4) return RT_ERR_INVALID;
             ctx->wideChosen = true;
             if (ctx->wideBvh == value) return RT_OK;
             ctx->wideBvh = value;

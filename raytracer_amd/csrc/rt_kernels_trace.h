@@ -104,7 +104,6 @@ __device__ __forceinline__ bool hasTie(const LaneRay &r) { return __float_as_int
 // Root references of the first models, copied to LDS by the traversal kernel: entering a model
 // then costs an LDS read instead of a round trip to memory on every ray's critical path.
 constexpr int kRootCache = 64;
-constexpr int32_t kNoRoot = (int32_t)0x80000000;   // model without nodes; not a valid child reference
 
 template <bool WIDE>
 __device__ __forceinline__ bool enterModel(const SceneView &sc, const int32_t *rootLds, LaneRay &r, int m) {

@@ -112,6 +112,7 @@ struct PathBuffers {
     // Four-wide traversal only: stack entries beyond the LDS part, [wave][overflowDepth][64].
     int32_t *overflow;
     uint32_t overflowDepth;
+    uint32_t overflowFrom;   // eight-wide traversal: stack entries below this number live in LDS
     // Four-wide traversal with exact ties: slots of rays that met two triangles of one model at the
     // same distance; they are traced again in the reference's visiting order.  The count is
     // stage's retrace.count (it may exceed the capacity: the surplus is not stored).

@@ -139,7 +139,7 @@ def test_wide_option_rebuilds_committed_scene():
         back, _ = b.readback()
         assert b.set_option(capi.RT_OPT_WIDE_BVH, 0) is None
         with pytest.raises(capi.RtError):
-            b.set_option(capi.RT_OPT_WIDE_BVH, 4)
+            b.set_option(capi.RT_OPT_WIDE_BVH, 5)
     finally:
         b.close()
     assert rel_rmse(got, ref) <= 1e-4
