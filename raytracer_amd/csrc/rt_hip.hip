@@ -1738,32 +1738,27 @@ int rt_set_frame(rt_ctx *ctx, const rt_camera *cam, const float sky_linear[3], i
     return RT_OK;
 }
 
-int rt_render(rt_ctx *ctx, uint32_t first_frame, uint32_t n_frames, uint32_t frame_stride) {
-    if (ctx == nullptr || frame_stride == 0) return RT_ERR_INVALID;
-    if (!ctx->committed || !ctx->frameSet || ctx->dAccum == nullptr) return RT_ERR_STATE;
-    if (n_frames == 0) return RT_OK;
-    RT_HIP(hipSetDevice(ctx->device));
-    const FrameParams &fp = ctx->fp;
-    const uint64_t totalPlanes = (uint64_t)n_frames * fp.S;
-    if (totalPlanes > 0xffffffffull) return RT_ERR_INVALID;
-    // A call of few paths takes the next stream of the frame pipeline; anything larger fills the chip
-    // by itself and stays on the context's own stream (its resolve pass still waits its turn).
-    int pipeNo = 0;
-    if (ctx->pipelineOn && totalPlanes * fp.npt <= ctx->pipelinePaths) {
-        pipeNo = ctx->nextPipe;
-        ctx->nextPipe = (ctx->nextPipe + 1) % rt_ctx::kPipes;
-        if (pipeNo > 0) {
-            rt_ctx::Pipe &pipe = ctx->pipes[pipeNo - 1];
-            if (ctx->pb.counters == nullptr) {
-                pipeNo = 0;   // the shared counters are created with the first pipe's buffers
-            } else if (pipe.stream == nullptr) {
-                if (hipStreamCreate(&pipe.stream) != hipSuccess) { pipe.stream = nullptr; (void)hipGetLastError(); pipeNo = 0; }
-                else pipe.pb.counters = ctx->pb.counters;
-            }
+// Stream `pipeNo` of the frame pipeline, created on first use; 0 (the context's own) when it cannot be had.
+static int usablePipe(rt_ctx *ctx, int pipeNo) {
+    if (pipeNo <= 0) return 0;
+    rt_ctx::Pipe &pipe = ctx->pipes[pipeNo - 1];
+    if (ctx->pb.counters == nullptr) return 0;   // the shared counters are created with the first pipe's buffers
+    if (pipe.stream == nullptr) {
+        if (hipStreamCreate(&pipe.stream) != hipSuccess) {
+            pipe.stream = nullptr;
+            (void)hipGetLastError();
+            return 0;
         }
+        pipe.pb.counters = ctx->pb.counters;
     }
+    return pipeNo;
+}
+
+// Queues sample planes [g0, g1) of a render call on stream `pipeNo`.
+static int renderPlanes(rt_ctx *ctx, int pipeNo, uint64_t g0, uint64_t g1, uint32_t first_frame, uint32_t frame_stride) {
+    const FrameParams &fp = ctx->fp;
     PipeScope onPipe(ctx, pipeNo);
-    int rc = ensurePathBuffers(ctx, totalPlanes * fp.npt);
+    int rc = ensurePathBuffers(ctx, (g1 - g0) * fp.npt);
     if (rc != RT_OK) return rc;
     if (pipeNo > 0 && ctx->wideNow) {
         // this pipe's copy of the part of the traversal stack that does not fit in LDS
@@ -1780,13 +1775,12 @@ int rt_render(rt_ctx *ctx, uint32_t first_frame, uint32_t n_frames, uint32_t fra
 
     hipEvent_t e0 = takeEvent(ctx), e1 = takeEvent(ctx);
     if (e0) hipEventRecord(e0, ctx->stream);
-
     // Batches never exceed the current ceiling even when a larger buffer is already held.
     const uint32_t planesPerBatch = std::max(1u, std::min(ctx->P, std::max(ctx->maxPaths, fp.npt)) / fp.npt);
-    for (uint64_t g = 0; g < totalPlanes; g += planesPerBatch) {
+    for (uint64_t g = g0; g < g1; g += planesPerBatch) {
         Batch bt;
         bt.g0 = (uint32_t)g;
-        bt.K = (uint32_t)std::min<uint64_t>(planesPerBatch, totalPlanes - g);
+        bt.K = (uint32_t)std::min<uint64_t>(planesPerBatch, g1 - g);
         bt.firstFrame = first_frame;
         bt.frameStride = frame_stride;
         bt.P = ctx->P;
@@ -1795,6 +1789,31 @@ int rt_render(rt_ctx *ctx, uint32_t first_frame, uint32_t n_frames, uint32_t fra
     }
     if (e1) hipEventRecord(e1, ctx->stream);
     if (e0 && e1) ctx->renderEvents.push_back({e0, e1});
+    return RT_OK;
+}
+
+int rt_render(rt_ctx *ctx, uint32_t first_frame, uint32_t n_frames, uint32_t frame_stride) {
+    if (ctx == nullptr || frame_stride == 0) return RT_ERR_INVALID;
+    if (!ctx->committed || !ctx->frameSet || ctx->dAccum == nullptr) return RT_ERR_STATE;
+    if (n_frames == 0) return RT_OK;
+    RT_HIP(hipSetDevice(ctx->device));
+    const FrameParams &fp = ctx->fp;
+    const uint64_t totalPlanes = (uint64_t)n_frames * fp.S;
+    if (totalPlanes > 0xffffffffull) return RT_ERR_INVALID;
+    int rc = RT_OK;
+    if (ctx->pipelineOn && totalPlanes * fp.npt <= ctx->pipelinePaths) {
+        // A call of few paths takes the next stream of the frame pipeline.
+        const int pipeNo = usablePipe(ctx, ctx->nextPipe);
+        ctx->nextPipe = (ctx->nextPipe + 1) % rt_ctx::kPipes;
+        rc = renderPlanes(ctx, pipeNo, 0, totalPlanes, first_frame, frame_stride);
+    } else {
+        // Anything larger fills the chip by itself and stays on the context's own stream (its resolve
+        // passes still wait their turn).  Dealing its sample planes to two or three streams, so that the
+        // drain tail of one share's kernels overlaps with another share's work, changed nothing
+        // (1920x1080 x 64 planes: 109.2-109.6 ms on one stream, 110.3 on two, 109.3 on three).
+        rc = renderPlanes(ctx, 0, 0, totalPlanes, first_frame, frame_stride);
+    }
+    if (rc != RT_OK) return rc;
     ctx->framesAccum += n_frames;
     uint64_t ownedPixels = (uint64_t)ctx->W * (uint64_t)ctx->H;
     if (fp.tileStride > 1) {
