@@ -331,6 +331,8 @@ def main():
                 out[key] = {"value": round(wst["rays"] / dt / 1e6, 3), "unit": "Mrays/s", "steps": 2, "ms_per_step": round(dt / 2 * 1e3, 3),
                             "trace_only_mrays_per_s": round(wst["rays"] / max(wst["trace_ms"] / 1e3, 1e-12) / 1e6, 2)}
             be.set_option(capi.RT_OPT_WIDE_BVH, 3)
+        if world == 1 and not args.no_optin:
+            out["one_frame_per_call"] = one_frame_per_call(scene, rtype, local_rank)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, scene, cam, rtype)
             # The other CPU baseline, the reference's own shaders on Mesa llvmpipe, cannot be produced here.
@@ -340,6 +342,39 @@ def main():
     be.close()
     if distributed:
         dist.destroy_process_group()
+
+
+def one_frame_per_call(scene, rtype, device):
+    """Informational, outside the timed region: the reference's own usage pattern on the same scene: ONE
+    progressive frame per render call (RayEngine::render in the main loop, src/main.cpp:163-202), 960x540,
+    rayPerPixel 1, 5 bounces.  Such calls cannot fill the chip one at a time; the library overlaps
+    consecutive calls on three streams (RT_OPT_PIPELINE) with the sum buffer updated in call order."""
+    from raytracer_amd import capi
+
+    out = {"what": "frames/s of 300 render calls of one 960x540 frame each (rayPerPixel 1, 5 bounces), synchronised once at the end"}
+    cam = capi.make_camera(width=960, height=540, bounces=5, ray_per_pixel=1)
+    for key, pipeline in (("frames_per_s", 1), ("frames_per_s_without_overlap", 0)):
+        be = capi.Backend(device)
+        try:
+            be.set_option(capi.RT_OPT_PIPELINE, pipeline)
+            be.upload_scene(scene)
+            be.resize(960, 540)
+            be.set_frame(cam, scene.sky, rtype)
+            for f in range(6):
+                be.render(first_frame=1 + f, n_frames=1, stride=1)
+            be.sync()
+            be.reset_stats()
+            t0 = time.perf_counter()
+            for f in range(300):
+                be.render(first_frame=7 + f, n_frames=1, stride=1)
+            be.sync()
+            dt = time.perf_counter() - t0
+            out[key] = round(300 / dt, 1)
+            if pipeline:
+                out["mrays_per_s"] = round(be.stats()["rays"] / dt / 1e6, 1)
+        finally:
+            be.close()
+    return out
 
 
 LIMITS_PROFILE = "profiles/r02_c_limits.json"
