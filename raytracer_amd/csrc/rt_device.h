@@ -60,6 +60,18 @@ struct __attribute__((aligned(16))) PackedTri {
     float ac[3]; int32_t ident;      // C - A,      identifier index inside the model (leaf order)
 };
 static_assert(sizeof(PackedTri) == 48, "triangle record must be 48 bytes");
+// Two triangles of one leaf of a four-wide tree with their components interleaved, so that each 16-byte
+// piece holds two aligned (first, second) pairs: the traversal kernel tests both with packed arithmetic.
+// A leaf with an odd number of triangles leaves the second half of its last pair zero (ident = kMiss): a
+// degenerate triangle that no ray hits.
+struct __attribute__((aligned(16))) TriPair {
+    float ax[2], ay[2];
+    float az[2], abx[2];
+    float aby[2], abz[2];
+    float acx[2], acy[2];
+    float acz[2]; int32_t ident[2];   // index into tris (what hit records carry)
+};
+static_assert(sizeof(TriPair) == 80, "triangle pair must be five 16-byte pieces");
 // What shading needs of a triangle besides PackedTri, under the same index: the vertex normals and
 // texture coordinates gathered from the vertex stream at commit time.  A hit then costs two
 // independent fetches (112 contiguous bytes) instead of the chain triangle -> identifier -> three
@@ -94,6 +106,7 @@ struct SceneView {
     const PackedTri *tris;
     const PackedShade *shade;   // [triangle], same index as tris
     const PackedTri *wtris;     // four-wide trees: the triangles in THEIR leaf order; `ident` holds the index into tris
+    const TriPair *wpairs;      // four-wide trees of scenes without alpha-cut textures: the leaves as triangle pairs (leaf references then count pairs)
     const ModelDesc *modelDesc;
     int32_t objectCount, modelsCount, lightSourcesCount;
 };

@@ -82,6 +82,7 @@ struct rt_ctx {
     PackedNode *dNodes = nullptr;
     WideNode *dWNodes = nullptr;    // four-wide tree (wideBvh only)
     Wide8Node *dW8Nodes = nullptr;  // eight-wide tree (wideBvh 4)
+    TriPair *dWPairs = nullptr;     // leaves of the four-wide trees as triangle pairs (scenes without alpha-cut textures)
     int wideBvh = 3;                // asked for: 0 off, 1 derived from the uploaded trees, 2 the library's own trees, 3 = 2 + ties re-traced in reference order, 4 = 3 on eight-wide trees
     bool wideChosen = false;        // by option or environment: then a scene the four-wide build declines is an error
     int wideNow = 0;                // in effect for the committed scene (0 when the default was declined for it)
@@ -966,6 +967,37 @@ int buildWideNodes(rt_ctx *ctx, std::vector<ModelDesc> &descs, std::vector<WideN
     return RT_OK;
 }
 
+// Re-packs the leaves of the four-wide trees as triangle pairs (TriPair) and rewrites every leaf
+// reference, in the nodes and in the models' roots, from (first triangle, triangles) to (first pair, pairs).
+void pairLeaves(std::vector<WideNode> &wnodes, std::vector<ModelDesc> &descs, const std::vector<PackedTri> &wtris, std::vector<TriPair> &wpairs) {
+    wpairs.clear();
+    wpairs.reserve(wtris.size() * 2 / 3 + 1);
+    auto paired = [&](int32_t ref) -> int32_t {
+        if (ref >= 0) return ref;
+        const uint32_t code = ~(uint32_t)ref, first = code >> 2, count = code & 3u;
+        if (count == 0u) return ref;
+        const uint32_t at = (uint32_t)wpairs.size(), pairs = (count + 1u) / 2u;
+        for (uint32_t p = 0; p < pairs; ++p) {
+            TriPair tp;
+            std::memset(&tp, 0, sizeof tp);
+            tp.ident[0] = tp.ident[1] = (int32_t)kMiss;
+            for (uint32_t h = 0; h < 2u && 2u * p + h < count; ++h) {
+                const PackedTri &t = wtris[(size_t)first + 2u * p + h];
+                tp.ax[h] = t.a[0]; tp.ay[h] = t.a[1]; tp.az[h] = t.a[2];
+                tp.abx[h] = t.ab[0]; tp.aby[h] = t.ab[1]; tp.abz[h] = t.ab[2];
+                tp.acx[h] = t.ac[0]; tp.acy[h] = t.ac[1]; tp.acz[h] = t.ac[2]; tp.ident[h] = t.ident;
+            }
+            wpairs.push_back(tp);
+        }
+        return ~(int32_t)((at << 2) | pairs);
+    };
+    for (WideNode &wn : wnodes) {
+        wn.c0 = paired(wn.c0); wn.c1 = paired(wn.c1); wn.c2 = paired(wn.c2); wn.c3 = paired(wn.c3);
+    }
+    for (ModelDesc &d : descs)
+        if (d.nodesCount > 0) d.wideRootRef = paired(d.wideRootRef);
+}
+
 // Eight-wide tree of every model (RT_OPT_WIDE_BVH 4), collapsed from the library's binary trees: a
 // node adopts the children of its child with the largest box until it has eight.  Layout and child
 // encoding: Wide8Node in rt_device.h.  The inner children of a node get consecutive node numbers and
@@ -1528,7 +1560,7 @@ void rt_destroy(rt_ctx *ctx) {
     }
     if (ctx->fence) hipEventDestroy(ctx->fence);
     for (float *p : ctx->dStream) if (p) hipFree(p);
-    void *owned[] = {ctx->dNodes, ctx->dWNodes, ctx->dW8Nodes, ctx->pb.overflow, ctx->pb.retrace, ctx->dWTris, ctx->dTris, ctx->dShade, ctx->dModelDesc, ctx->accumExternal ? nullptr : (void *)ctx->dAccum, ctx->dPartial,
+    void *owned[] = {ctx->dNodes, ctx->dWNodes, ctx->dW8Nodes, ctx->dWPairs, ctx->pb.overflow, ctx->pb.retrace, ctx->dWTris, ctx->dTris, ctx->dShade, ctx->dModelDesc, ctx->accumExternal ? nullptr : (void *)ctx->dAccum, ctx->dPartial,
                      ctx->pb.rays, ctx->pb.hits, ctx->pb.stA, ctx->pb.stB, ctx->pb.neeA, ctx->pb.neeB, ctx->pb.neeC,
                      ctx->pb.qExt[0], ctx->pb.qExt[1], ctx->pb.qShadow, ctx->pb.stages, ctx->pb.counters};
     for (void *p : owned) if (p) hipFree(p);
@@ -1607,8 +1639,12 @@ static int commitScene(rt_ctx *ctx, int objectCount, int modelsCount, int lightS
         if (rc == RT_ERR_SCENE && !ctx->wideChosen) ctx->wideNow = 0;
         else if (rc != RT_OK) return rc;
     }
+    std::vector<TriPair> wpairs;
+    if (ctx->wideNow >= 1 && ctx->wideNow <= 3 && !ctx->hasAlphaTest) pairLeaves(wnodes, descs, wtris, wpairs);
     lap("wide trees", mark);
     if (ctx->wideNow) {
+        if ((rc = devAlloc(ctx, &ctx->dWPairs, wpairs.size())) != RT_OK) return rc;
+        if (!wpairs.empty()) RT_HIP(hipMemcpy(ctx->dWPairs, wpairs.data(), wpairs.size() * sizeof(TriPair), hipMemcpyHostToDevice));
         if ((rc = devAlloc(ctx, &ctx->dWTris, wtris.size())) != RT_OK) return rc;
         if (!wtris.empty()) RT_HIP(hipMemcpy(ctx->dWTris, wtris.data(), wtris.size() * sizeof(PackedTri), hipMemcpyHostToDevice));
         if ((rc = devAlloc(ctx, &ctx->dWNodes, wnodes.size())) != RT_OK) return rc;
@@ -1651,6 +1687,7 @@ static int commitScene(rt_ctx *ctx, int objectCount, int modelsCount, int lightS
     v.nodes = ctx->dNodes;
     v.wnodes = ctx->wideNow ? ctx->dWNodes : nullptr;
     v.w8nodes = ctx->wideNow == 4 ? ctx->dW8Nodes : nullptr;
+    v.wpairs = (ctx->wideNow >= 1 && ctx->wideNow <= 3 && !ctx->hasAlphaTest) ? ctx->dWPairs : nullptr;
     v.wtris = ctx->wideNow ? ctx->dWTris : nullptr;
     v.tris = ctx->dTris;
     v.shade = ctx->dShade;

@@ -105,7 +105,9 @@ __device__ __forceinline__ bool hasTie(const LaneRay &r) { return __float_as_int
 // then costs an LDS read instead of a round trip to memory on every ray's critical path.
 constexpr int kRootCache = 64;
 
-template <bool WIDE>
+// LEAN (the write-through instances of k_trace): the lane keeps neither the model's best hit nor a second
+// copy of the closest distance; "this model has a hit" is bit 31 of r.model, cleared here.
+template <bool WIDE, bool LEAN = false>
 __device__ __forceinline__ bool enterModel(const SceneView &sc, const int32_t *rootLds, LaneRay &r, int m) {
     for (; m < sc.modelsCount; ++m) {
         int32_t root;
@@ -119,11 +121,13 @@ __device__ __forceinline__ bool enterModel(const SceneView &sc, const int32_t *r
         r.model = m;
         r.ref = root;
         r.sp = 0;
-        r.tModel = 1e20f;
-        r.maxT = r.closest;
-        r.mBest = kMiss;
-        r.mU = 0.0f;
-        r.mV = 0.0f;
+        if (!LEAN) {
+            r.tModel = 1e20f;
+            r.maxT = r.closest;
+            r.mBest = kMiss;
+            r.mU = 0.0f;
+            r.mV = 0.0f;
+        }
         r.pendTri = kMiss;
         r.resume = 0u;
         return true;
@@ -229,6 +233,9 @@ __device__ __forceinline__ void intersectPrimitives(const SceneView &sc, LaneRay
 template <bool COUNT, int STACK, bool ALPHA, bool PRIMS, bool ROOTS, bool WIDE, bool RETRACE = false>
 __global__ __launch_bounds__(kBlock, COUNT ? kCountingWaves : WIDE ? (ALPHA ? RT_WWIDE_ALPHA : RT_WWIDE)
                                           : (STACK <= 20 ? (ALPHA ? RT_WALPHA : PRIMS ? 7 : RT_W20) : STACK <= 24 ? (ALPHA ? (RT_WALPHA < 6 ? RT_WALPHA : 6) : 6) : 5)) void k_trace(SceneView sc, PathBuffers pb, int extParity, int stage, int refillLanes, int innerShare) {
+    // Pair-leaf instances without analytic primitives write a hit record the moment a triangle is accepted and
+    // keep only "this model has a hit" (mBest != kMiss), not the hit's u, v and triangle: three registers fewer.
+    constexpr bool kWriteThrough = WIDE && !ALPHA && !PRIMS;
     __shared__ int32_t stackLds[kBlock / 64][STACK][64];
     // ROOTS variants (scenes with more than two models): the models' root references sit in LDS.
     // With one or two models the descriptor loads hit the L1 and the plain variant is faster
@@ -356,6 +363,55 @@ __global__ __launch_bounds__(kBlock, COUNT ? kCountingWaves : WIDE ? (ALPHA ? RT
         return false;
     };
 
+    // The same test on the two triangles of a TriPair at once; the second is taken up after the first, as
+    // two consecutive triangles of a leaf are.
+    auto modelHasHit = [&]() -> bool { return kWriteThrough ? r.model < 0 : r.mBest != kMiss; };
+    auto testPair = [&](const float4v &q0, const float4v &q1, const float4v &q2, const float4v &q3, const float4v &q4) {
+        const float2v rdx = {r.rd.x, r.rd.x}, rdy = {r.rd.y, r.rd.y}, rdz = {r.rd.z, r.rd.z};
+        // ao = ro - A (the vertex is not needed afterwards)
+        const float2v aox = (float2v){r.ro.x, r.ro.x} - (float2v){q0.x, q0.y}, aoy = (float2v){r.ro.y, r.ro.y} - (float2v){q0.z, q0.w},
+                      aoz = (float2v){r.ro.z, r.ro.z} - (float2v){q1.x, q1.y};
+        const float2v abx = {q1.z, q1.w}, aby = {q2.x, q2.y}, abz = {q2.z, q2.w};
+        const float2v acx = {q3.x, q3.y}, acy = {q3.z, q3.w}, acz = {q4.x, q4.y};
+        // nrm = cross(ab, ac), det = -dot(rd, nrm), dot(ao, nrm)
+        const float2v nx = aby * acz - acy * abz, ny = abz * acx - acz * abx, nz = abx * acy - acx * aby;
+        const float2v det = -(rdx * nx + rdy * ny + rdz * nz);
+        const float2v tn = aox * nx + aoy * ny + aoz * nz;
+        __builtin_amdgcn_sched_barrier(0);   // keeps the normal's registers from living on beside what follows
+        // dao = cross(ao, rd), dot(ac, dao), -dot(ab, dao)
+        const float2v dx = aoy * rdz - rdy * aoz, dy = aoz * rdx - rdz * aox, dz = aox * rdy - rdx * aoy;
+        const float2v un = acx * dx + acy * dy + acz * dz;
+        const float2v vn = -(abx * dx + aby * dy + abz * dz);
+        auto finish = [&](float detK, float tnK, float unK, float vnK, uint32_t identK) {
+            if (COUNT && identK != kMiss) cntTris++;
+            if (abs_(detK) < 1e-8f) return;       // also the empty half of a pair (all zeros)
+            const float invDet = 1.0f / detK;
+            const float t = tnK * invDet;
+            if (t < 0.0f || t > r.maxT) return;
+            const bool sameModelTie = modelHasHit() && t == r.maxT;
+            const float u = unK * invDet;
+            const float v = vnK * invDet;
+            if (u < 0.0f || v < 0.0f || u + v > 1.0f) return;
+            if (sameModelTie) {
+                markTie(r);
+                return;
+            }
+            r.maxT = t;
+            if (kWriteThrough) {
+                r.model |= (int32_t)0x80000000;
+                HitRec rec;
+                rec.t = t; rec.u = u; rec.v = v; rec.id = identK;
+                *reinterpret_cast<float4 *>(&pb.hits[r.slot]) = *reinterpret_cast<const float4 *>(&rec);
+            } else {
+                r.mBest = identK;
+                r.mU = u;
+                r.mV = v;
+            }
+        };
+        finish(det.x, tn.x, un.x, vn.x, __float_as_uint(q4.z));
+        finish(det.y, tn.y, un.y, vn.y, __float_as_uint(q4.w));
+    };
+
     for (;;) {
         if (COUNT && active) maxSp = max(maxSp, (uint32_t)r.sp);
         const unsigned long long idleMask = __ballot(!active);
@@ -426,10 +482,11 @@ __global__ __launch_bounds__(kBlock, COUNT ? kCountingWaves : WIDE ? (ALPHA ? RT
                         // overwritten whenever a model ends with a closer hit, so the best
                         // hit need not be carried in registers.
                         r.closest = 1e20f;
+                        if (kWriteThrough) r.maxT = 1e20f;   // one distance for the whole ray: it only ever shrinks
                         HitRec rec;
                         rec.t = 1e20f; rec.u = 0.0f; rec.v = 0.0f; rec.id = kMiss;
                         *reinterpret_cast<float4 *>(&pb.hits[r.slot]) = *reinterpret_cast<const float4 *>(&rec);
-                        active = enterModel<WIDE>(sc, rootLds, r, 0);
+                        active = enterModel<WIDE, kWriteThrough>(sc, rootLds, r, 0);
                     }
                 }
             }
@@ -511,23 +568,17 @@ __global__ __launch_bounds__(kBlock, COUNT ? kCountingWaves : WIDE ? (ALPHA ? RT
             bool parked = false;
             if (COUNT) cntLeaves++;
             if (WIDE && !ALPHA) {
-                // The usual leaf holds one or two triangles: fetch both in one round trip (the binary
-                // variants have no registers to spare for this: -10 % there, +2 % here).
-                const float4v *tp = reinterpret_cast<const float4v *>(&sc.wtris[first]);
-                if (ntri > 0u) {
-                    const bool two = ntri > 1u;
-                    float4v a0 = tp[0], a1 = tp[1], a2 = tp[2];
-                    float4v b0 = a0, b1 = a1, b2 = a2;
-                    if (two) { b0 = tp[3]; b1 = tp[4]; b2 = tp[5]; }
-                    pinLoaded(a0, a1, a2);
-                    pinLoaded(b0, b1, b2);
-                    testTriangle(first, asFloat4(a0), asFloat4(a1), asFloat4(a2));
-                    if (two) testTriangle(first + 1u, asFloat4(b0), asFloat4(b1), asFloat4(b2));
-                    for (uint32_t k = 2u; k < ntri; ++k) {
-                        float4v q0 = tp[3 * k], q1 = tp[3 * k + 1], q2 = tp[3 * k + 2];
-                        pinLoaded(q0, q1, q2);
-                        testTriangle(first + k, asFloat4(q0), asFloat4(q1), asFloat4(q2));
-                    }
+                // Leaves of the four-wide trees hold PAIRS of triangles with their components interleaved
+                // (TriPair): one round trip fetches both, and every product and sum of the two
+                // Moeller-Trumbore tests up to the divisions is one packed instruction for both triangles
+                // (each component is the same IEEE operation as in the one-triangle form, in the same order).
+                for (uint32_t k = 0u; k < ntri; ++k) {     // ntri counts pairs here: one, rarely two
+                    const float4v *tp = reinterpret_cast<const float4v *>(&sc.wpairs[first + k]);
+                    float4v q0 = tp[0], q1 = tp[1], q2 = tp[2];
+                    float4v q3 = tp[3], q4 = tp[4];
+                    pinLoaded(q0, q1, q2);
+                    asm volatile("" : "+v"(q3), "+v"(q4));
+                    testPair(q0, q1, q2, q3, q4);
                 }
             } else {
                 for (uint32_t k = ALPHA ? r.resume : 0u; k < ntri; ++k) {
@@ -544,7 +595,7 @@ __global__ __launch_bounds__(kBlock, COUNT ? kCountingWaves : WIDE ? (ALPHA ? RT
             if (!parked) {
                 if (ALPHA) r.resume = 0u;
                 pop = true;
-                occluded = WIDE ? (r.mBest != kMiss && r.maxT < abs_(r.tStop)) : (r.tModel < r.tStop);
+                occluded = WIDE ? (modelHasHit() && r.maxT < abs_(r.tStop)) : (r.tModel < r.tStop);
             }
         }
         if (pop) {
@@ -553,20 +604,20 @@ __global__ __launch_bounds__(kBlock, COUNT ? kCountingWaves : WIDE ? (ALPHA ? RT
                 if (WIDE && r.sp >= STACK) r.ref = overflow[(size_t)(r.sp - STACK) * 64];
                 else r.ref = *stackSlot(r.sp);
             } else {
-                if (r.mBest != kMiss) {
+                if (!kWriteThrough && r.mBest != kMiss) {
                     const float tHit = WIDE ? r.maxT : r.tModel;
                     r.closest = tHit;
                     if (PRIMS) {
                         r.bestId = r.mBest;
                         r.bestU = r.mU;
                         r.bestV = r.mV;
-                    } else {
+                    } else if (!kWriteThrough) {
                         HitRec rec;
                         rec.t = tHit; rec.u = r.mU; rec.v = r.mV; rec.id = r.mBest;
                         *reinterpret_cast<float4 *>(&pb.hits[r.slot]) = *reinterpret_cast<const float4 *>(&rec);
                     }
                 }
-                if (occluded || !enterModel<WIDE>(sc, rootLds, r, r.model + 1)) {
+                if (occluded || !enterModel<WIDE, kWriteThrough>(sc, rootLds, r, (r.model & 0x7fffffff) + 1)) {
                     if (PRIMS) {
                         uint32_t id = r.bestId;
                         if (id != kMiss && (id & kPrimBit) == 0u && !(r.afterPrimitives > r.closest)) id |= kNoTexBit;
