@@ -106,7 +106,7 @@ int rt_set_frame(rt_ctx *ctx, const rt_camera *cam, const float sky_linear[3], i
  * src/RayEngine.cpp:28-42) for frameCount = first_frame .. first_frame+n_frames-1
  * in steps of frame_stride (sample-split sharding uses stride = number of GPUs).
  * Adds each frame's colour into the sum buffer.  Asynchronous: the call queues its kernels and
- * returns.  Calls of few paths (up to 4 Mi: one progressive frame of a viewer, as the reference's main
+ * returns.  Calls of few paths (up to 1 Mi: one progressive frame of a viewer, as the reference's main
  * loop issues them, src/main.cpp:163-202) are queued on three streams in turn, each with path
  * buffers of its own, so that consecutive calls overlap on the device; the passes that add to the sum
  * buffer are chained in call order, so the buffer holds the same bits as without the overlap

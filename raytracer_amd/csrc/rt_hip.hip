@@ -147,7 +147,8 @@ struct rt_ctx {
     hipEvent_t accumFence = nullptr;   // null: nothing pending on the sum buffer
     int nextPipe = 0;
     bool pipelineOn = true;            // RT_OPT_PIPELINE / env RT_PIPELINE
-    uint64_t pipelinePaths = 4u << 20; // calls of at most this many paths are pipelined
+    uint64_t pipelinePaths = 1u << 20; // calls of at most this many paths are pipelined (a 1280x720 frame; a call of 4 Mi paths fills the chip
+                                       // alone and only loses by rotating through three sets of buffers: 3.6 -> 4.6 ms)
 
     std::vector<std::pair<hipEvent_t, hipEvent_t>> traceEvents, renderEvents;
     std::vector<hipEvent_t> eventPool;
