@@ -141,7 +141,10 @@ struct rt_ctx {
         uint32_t overflowWords = 0;
         hipEvent_t fence = nullptr;
     };
-    static constexpr int kPipes = 3;
+#ifndef RT_PIPES
+#define RT_PIPES 3
+#endif
+    static constexpr int kPipes = RT_PIPES;
     Pipe pipes[kPipes - 1];
     hipEvent_t fence = nullptr;        // pipe 0's
     hipEvent_t accumFence = nullptr;   // null: nothing pending on the sum buffer
