@@ -1309,7 +1309,7 @@ void launchTrace(rt_ctx *ctx, int extParity, int stage, uint64_t maxRays) {
         wavesPerSimd = RT_W8;
     } else if (ctx->wideNow) {
         fn = wideVariants[ctx->countersOn ? 1 : 0][ctx->modelsCount > 2 ? 1 : 0][ctx->hasAlphaTest ? 1 : 0][prims ? 1 : 0];
-        wavesPerSimd = ctx->hasAlphaTest ? RT_WWIDE_ALPHA : RT_WWIDE;
+        wavesPerSimd = (ctx->hasAlphaTest && prims) ? RT_WWIDE_ALPHA : RT_WWIDE;
     } else {
         const bool rootsInLds = ctx->modelsCount > 2 && depthClass < 2 && !ctx->countersOn;
         fn = rootsInLds ? rootVariants[depthClass][ctx->hasAlphaTest ? 1 : 0][prims ? 1 : 0]

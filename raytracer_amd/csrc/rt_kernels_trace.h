@@ -231,11 +231,11 @@ __device__ __forceinline__ void intersectPrimitives(const SceneView &sc, LaneRay
 // ray but slower, because lanes then mix the small models' leaves with the large model's inner
 // nodes and the two phases of the loop run emptier.)
 template <bool COUNT, int STACK, bool ALPHA, bool PRIMS, bool ROOTS, bool WIDE, bool RETRACE = false>
-__global__ __launch_bounds__(kBlock, COUNT ? kCountingWaves : WIDE ? (ALPHA ? RT_WWIDE_ALPHA : RT_WWIDE)
+__global__ __launch_bounds__(kBlock, COUNT ? kCountingWaves : WIDE ? ((ALPHA && PRIMS) ? RT_WWIDE_ALPHA : RT_WWIDE)
                                           : (STACK <= 20 ? (ALPHA ? RT_WALPHA : PRIMS ? 7 : RT_W20) : STACK <= 24 ? (ALPHA ? (RT_WALPHA < 6 ? RT_WALPHA : 6) : 6) : 5)) void k_trace(SceneView sc, PathBuffers pb, int extParity, int stage, int refillLanes, int innerShare) {
-    // Pair-leaf instances without analytic primitives write a hit record the moment a triangle is accepted and
+    // Four-wide instances without analytic primitives write a hit record the moment a triangle is accepted and
     // keep only "this model has a hit" (mBest != kMiss), not the hit's u, v and triangle: three registers fewer.
-    constexpr bool kWriteThrough = WIDE && !ALPHA && !PRIMS;
+    constexpr bool kWriteThrough = WIDE && !PRIMS;
     __shared__ int32_t stackLds[kBlock / 64][STACK][64];
     // ROOTS variants (scenes with more than two models): the models' root references sit in LDS.
     // With one or two models the descriptor loads hit the L1 and the plain variant is faster
@@ -322,6 +322,21 @@ __global__ __launch_bounds__(kBlock, COUNT ? kCountingWaves : WIDE ? (ALPHA ? RT
         r.ref = c0;
         return false;
     };
+    auto modelHasHit = [&]() -> bool { return kWriteThrough ? r.model < 0 : r.mBest != kMiss; };
+    // Records an accepted hit: in the lane, or (write-through instances) in the ray's hit record at once.
+    auto acceptHit = [&](float t, float u, float v, uint32_t tri) {
+        r.maxT = t;
+        if (kWriteThrough) {
+            r.model |= (int32_t)0x80000000;
+            HitRec rec;
+            rec.t = t; rec.u = u; rec.v = v; rec.id = tri;
+            *reinterpret_cast<float4 *>(&pb.hits[r.slot]) = *reinterpret_cast<const float4 *>(&rec);
+        } else {
+            r.mBest = tri;
+            r.mU = u;
+            r.mV = v;
+        }
+    };
     // Möller–Trumbore as hitTriangle writes it (src/RayScene.cpp:510-545); returns true when the
     // hit waits for its alpha-cut lookup.
     auto testTriangle = [&](uint32_t ti, const float4 &q0, const float4 &q1, const float4 &q2) -> bool {
@@ -338,7 +353,7 @@ __global__ __launch_bounds__(kBlock, COUNT ? kCountingWaves : WIDE ? (ALPHA ? RT
         // A later model's triangle at exactly the closest distance so far replaces the hit, a
         // triangle of the same model does not (src/RayScene.cpp:535, :405-406).  The four-wide walk
         // keeps one distance for both tests: maxT is this model's hit once mBest is set.
-        const bool sameModelTie = WIDE && r.mBest != kMiss && t == r.maxT;
+        const bool sameModelTie = WIDE && modelHasHit() && t == r.maxT;
         if (!WIDE && t >= r.tModel) return false;
         const float u = dot(ac, dao) * invDet;
         const float v = -dot(ab, dao) * invDet;
@@ -356,16 +371,12 @@ __global__ __launch_bounds__(kBlock, COUNT ? kCountingWaves : WIDE ? (ALPHA ? RT
             return true;
         }
         if (!WIDE) r.tModel = t;   // the four-wide walk keeps its closest hit in maxT alone
-        r.maxT = t;
-        r.mBest = WIDE ? (uint32_t)__float_as_int(q2.w) : ti;   // wide records carry the index into tris
-        r.mU = u;
-        r.mV = v;
+        acceptHit(t, u, v, WIDE ? (uint32_t)__float_as_int(q2.w) : ti);   // wide records carry the index into tris
         return false;
     };
 
     // The same test on the two triangles of a TriPair at once; the second is taken up after the first, as
     // two consecutive triangles of a leaf are.
-    auto modelHasHit = [&]() -> bool { return kWriteThrough ? r.model < 0 : r.mBest != kMiss; };
     auto testPair = [&](const float4v &q0, const float4v &q1, const float4v &q2, const float4v &q3, const float4v &q4) {
         const float2v rdx = {r.rd.x, r.rd.x}, rdy = {r.rd.y, r.rd.y}, rdz = {r.rd.z, r.rd.z};
         // ao = ro - A (the vertex is not needed afterwards)
@@ -396,17 +407,7 @@ __global__ __launch_bounds__(kBlock, COUNT ? kCountingWaves : WIDE ? (ALPHA ? RT
                 markTie(r);
                 return;
             }
-            r.maxT = t;
-            if (kWriteThrough) {
-                r.model |= (int32_t)0x80000000;
-                HitRec rec;
-                rec.t = t; rec.u = u; rec.v = v; rec.id = identK;
-                *reinterpret_cast<float4 *>(&pb.hits[r.slot]) = *reinterpret_cast<const float4 *>(&rec);
-            } else {
-                r.mBest = identK;
-                r.mU = u;
-                r.mV = v;
-            }
+            acceptHit(t, u, v, identK);
         };
         finish(det.x, tn.x, un.x, vn.x, __float_as_uint(q4.z));
         finish(det.y, tn.y, un.y, vn.y, __float_as_uint(q4.w));
@@ -513,10 +514,7 @@ __global__ __launch_bounds__(kBlock, COUNT ? kCountingWaves : WIDE ? (ALPHA ? RT
                     const uint32_t hitTri = WIDE ? (uint32_t)sc.wtris[r.pendTri].ident : r.pendTri;
                     if (!alphaCutRejects(sc, hitTri, r.ro, r.rd, r.pendT)) {
                         if (!WIDE) r.tModel = r.pendT;
-                        r.maxT = r.pendT;
-                        r.mBest = hitTri;
-                        r.mU = r.pendU;
-                        r.mV = r.pendV;
+                        acceptHit(r.pendT, r.pendU, r.pendV, hitTri);
                     }
                     r.resume = r.pendTri - ((~(uint32_t)r.ref) >> 2) + 1u;
                     r.pendTri = kMiss;

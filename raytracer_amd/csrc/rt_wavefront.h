@@ -23,7 +23,8 @@ namespace {
 #define RT_WWIDE 7     // waves/SIMD of the four-wide variants (72 VGPRs with 40 B of spills: +4 % over 6 waves without)
 #endif
 #ifndef RT_WWIDE_ALPHA
-#define RT_WWIDE_ALPHA 6   // alpha-cut four-wide variants: 80 VGPRs with 12-28 B of spills, +5 % over 5 waves without
+#define RT_WWIDE_ALPHA 6   // alpha-cut four-wide variants WITH analytic primitives: 80 VGPRs with 28 B of spills (the ones without
+                           // primitives write hit records through and fit RT_WWIDE waves with 12 B: interior 4K +4 % over 6 waves)
 #endif
 constexpr int kStackDepth = 32;      // int stack[32], src/RayScene.cpp:682
 #ifndef RT_WSTACK
