@@ -233,9 +233,10 @@ __device__ __forceinline__ void intersectPrimitives(const SceneView &sc, LaneRay
 template <bool COUNT, int STACK, bool ALPHA, bool PRIMS, bool ROOTS, bool WIDE, bool RETRACE = false>
 __global__ __launch_bounds__(kBlock, COUNT ? kCountingWaves : WIDE ? ((ALPHA && PRIMS) ? RT_WWIDE_ALPHA : RT_WWIDE)
                                           : (STACK <= 20 ? (ALPHA ? RT_WALPHA : PRIMS ? 7 : RT_W20) : STACK <= 24 ? (ALPHA ? (RT_WALPHA < 6 ? RT_WALPHA : 6) : 6) : 5)) void k_trace(SceneView sc, PathBuffers pb, int extParity, int stage, int refillLanes, int innerShare) {
-    // Four-wide instances without analytic primitives write a hit record the moment a triangle is accepted and
-    // keep only "this model has a hit" (mBest != kMiss), not the hit's u, v and triangle: three registers fewer.
-    constexpr bool kWriteThrough = WIDE && !PRIMS;
+    // Four-wide instances write a hit record the moment a hit is accepted (the primitives' best hit when the ray
+    // starts, then every accepted triangle) and keep only "this model has a hit" (bit 31 of the model number),
+    // not the best hit's u, v and id nor a second copy of the closest distance: three to seven registers fewer.
+    constexpr bool kWriteThrough = WIDE;
     __shared__ int32_t stackLds[kBlock / 64][STACK][64];
     // ROOTS variants (scenes with more than two models): the models' root references sit in LDS.
     // With one or two models the descriptor loads hit the L1 and the plain variant is faster
@@ -324,10 +325,12 @@ __global__ __launch_bounds__(kBlock, COUNT ? kCountingWaves : WIDE ? ((ALPHA && 
     };
     auto modelHasHit = [&]() -> bool { return kWriteThrough ? r.model < 0 : r.mBest != kMiss; };
     // Records an accepted hit: in the lane, or (write-through instances) in the ray's hit record at once.
-    auto acceptHit = [&](float t, float u, float v, uint32_t tri) {
+    auto acceptHit = [&](float t, float u, float v, uint32_t tri) {   // (tri by value: the no-texture mark is added to the copy)
         r.maxT = t;
         if (kWriteThrough) {
             r.model |= (int32_t)0x80000000;
+            // a model hit that only ties the closest primitive takes no textures (`startClosest > closest`, src/RayScene.cpp:763)
+            if (PRIMS && !(r.afterPrimitives > t)) tri |= kNoTexBit;
             HitRec rec;
             rec.t = t; rec.u = u; rec.v = v; rec.id = tri;
             *reinterpret_cast<float4 *>(&pb.hits[r.slot]) = *reinterpret_cast<const float4 *>(&rec);
@@ -470,7 +473,14 @@ __global__ __launch_bounds__(kBlock, COUNT ? kCountingWaves : WIDE ? ((ALPHA && 
                     }
                     // (four-wide: the sign is the tie mark; no hit is nearer than a stop distance <= 0 either way)
                     r.tStop = WIDE ? (r1.w > 0.0f ? r1.w : 0.0f) : r1.w;
-                    if (PRIMS) {
+                    if (PRIMS && kWriteThrough) {
+                        intersectPrimitives<COUNT>(sc, r, cntTris);
+                        HitRec rec;    // the primitives' answer; accepted triangles overwrite it
+                        rec.t = r.closest; rec.u = r.bestU; rec.v = r.bestV; rec.id = r.bestId;
+                        *reinterpret_cast<float4 *>(&pb.hits[r.slot]) = *reinterpret_cast<const float4 *>(&rec);
+                        r.maxT = r.closest;
+                        active = !(r.closest < r.tStop) && enterModel<WIDE, true>(sc, rootLds, r, 0);
+                    } else if (PRIMS) {
                         intersectPrimitives<COUNT>(sc, r, cntTris);
                         active = !(r.closest < r.tStop) && enterModel<WIDE>(sc, rootLds, r, 0);
                         if (!active) {   // no models (or already occluded): the primitive result is final
@@ -616,7 +626,7 @@ __global__ __launch_bounds__(kBlock, COUNT ? kCountingWaves : WIDE ? ((ALPHA && 
                     }
                 }
                 if (occluded || !enterModel<WIDE, kWriteThrough>(sc, rootLds, r, (r.model & 0x7fffffff) + 1)) {
-                    if (PRIMS) {
+                    if (PRIMS && !kWriteThrough) {
                         uint32_t id = r.bestId;
                         if (id != kMiss && (id & kPrimBit) == 0u && !(r.afterPrimitives > r.closest)) id |= kNoTexBit;
                         HitRec rec;
