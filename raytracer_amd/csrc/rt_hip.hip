@@ -1796,13 +1796,12 @@ static int usablePipe(rt_ctx *ctx, int pipeNo) {
 }
 
 // Queues sample planes [g0, g1) of a render call on stream `pipeNo`.
-static int renderPlanes(rt_ctx *ctx, int pipeNo, uint64_t g0, uint64_t g1, uint32_t first_frame, uint32_t frame_stride) {
-    const FrameParams &fp = ctx->fp;
-    PipeScope onPipe(ctx, pipeNo);
-    int rc = ensurePathBuffers(ctx, (g1 - g0) * fp.npt);
+// Device memory stream `pipeNo` needs for a call of `paths` paths: its path buffers and, beyond pipe 0,
+// its own copy of the part of the traversal stack that does not fit in LDS.  Call inside a PipeScope.
+static int preparePipe(rt_ctx *ctx, const PipeScope &onPipe, int pipeNo, uint64_t paths) {
+    int rc = ensurePathBuffers(ctx, paths);
     if (rc != RT_OK) return rc;
     if (pipeNo > 0 && ctx->wideNow) {
-        // this pipe's copy of the part of the traversal stack that does not fit in LDS
         const rt_ctx::Pipe &first = *onPipe.pipe;   // holds pipe 0's state while the scope lasts
         if (ctx->pb.overflow == nullptr || ctx->overflowWords < first.overflowWords) {
             const size_t waves = (size_t)ctx->numCUs * std::max(std::max(RT_WWIDE, RT_WWIDE_ALPHA), RT_W8) * (kBlock / 64);
@@ -1812,6 +1811,14 @@ static int renderPlanes(rt_ctx *ctx, int pipeNo, uint64_t g0, uint64_t g1, uint3
         ctx->pb.overflowDepth = first.pb.overflowDepth;
         ctx->pb.overflowFrom = first.pb.overflowFrom;
     }
+    return RT_OK;
+}
+
+static int renderPlanes(rt_ctx *ctx, int pipeNo, uint64_t g0, uint64_t g1, uint32_t first_frame, uint32_t frame_stride) {
+    const FrameParams &fp = ctx->fp;
+    PipeScope onPipe(ctx, pipeNo);
+    int rc = preparePipe(ctx, onPipe, pipeNo, (g1 - g0) * fp.npt);
+    if (rc != RT_OK) return rc;
     boundEvents(ctx);
 
     hipEvent_t e0 = takeEvent(ctx), e1 = takeEvent(ctx);
@@ -1875,7 +1882,17 @@ int rt_reserve(rt_ctx *ctx, uint32_t n_frames) {
     const uint64_t totalPlanes = (uint64_t)n_frames * ctx->fp.S;
     if (totalPlanes > 0xffffffffull) return RT_ERR_INVALID;
     RT_HIP(syncAllStreams(ctx));   // the buffers may be in use by queued work
-    return ensurePathBuffers(ctx, totalPlanes * ctx->fp.npt);
+    const uint64_t paths = totalPlanes * ctx->fp.npt;
+    int rc = ensurePathBuffers(ctx, paths);
+    // Calls of this size rotate through the streams of the frame pipeline: each gets its buffers now.
+    if (rc == RT_OK && ctx->pipelineOn && paths <= ctx->pipelinePaths)
+        for (int k = 1; k < rt_ctx::kPipes && rc == RT_OK; ++k) {
+            const int pipeNo = usablePipe(ctx, k);
+            if (pipeNo == 0) break;
+            PipeScope onPipe(ctx, pipeNo);
+            rc = preparePipe(ctx, onPipe, pipeNo, paths);
+        }
+    return rc;
 }
 
 int rt_reset_accum(rt_ctx *ctx) {

@@ -90,3 +90,23 @@ def test_pipeline_with_resets_display_and_scene_changes():
             b.close()
     for a, c in zip(results[True], results[False]):
         assert np.array_equal(np.asarray(a).view(np.uint8), np.asarray(c).view(np.uint8))
+
+
+def test_reserve_prepares_every_stream_of_the_pipeline():
+    """rt_reserve for a call size that the pipeline rotates over its streams sizes the buffers of all of
+    them; the frames that follow give the same image as without the reservation."""
+    W, H = 200, 120
+    scene = capi.Scene("mixed", nu=64, nv=12)
+    cam = capi.make_camera(width=W, height=H, bounces=3, ray_per_pixel=1)
+    images = []
+    for reserve in (True, False):
+        b = _backend(scene, W, H, cam, capi.RT_TYPE_RGB, True)
+        try:
+            if reserve:
+                b.reserve(1)
+            for f in range(7):
+                b.render(1 + f, 1, 1)
+            images.append(b.readback()[0])
+        finally:
+            b.close()
+    assert np.array_equal(images[0].view(np.uint32), images[1].view(np.uint32))
