@@ -148,6 +148,21 @@ int rt_display_rgba8(rt_ctx *ctx, uint8_t *rgba8, size_t bytes);
  * on one GPU race.  Synchronises. */
 int rt_display_rgba8_noalloc(rt_ctx *ctx, uint8_t *rgba8, size_t bytes);
 
+/* The screen pass without the wait, for a viewer that shows every frame as the reference's main loop does
+ * (src/main.cpp:163-202: render one frame, draw the tonemapped quad, swap; in GL both are queued commands
+ * and the loop runs ahead of the device).  rt_display_rgba8_begin queues the pass and the copy into `rgba8`
+ * behind every frame queued so far and returns; frames queued afterwards overlap with them, except that
+ * their additions to the sum buffer wait until the pass has read it.  rt_display_rgba8_end(slot) blocks
+ * until `rgba8` of that slot's last begin holds the frame.  Four slots (0..3), each with a staging frame
+ * on the device (allocated at a slot's first use at a resolution); a slot that was begun must be ended
+ * before it is begun again (RT_ERR_STATE otherwise).  `rgba8` must stay valid until the end call and
+ * should be pinned host memory or device memory: a copy into pageable memory makes begin wait for it.
+ * A viewer keeps two or three frames in flight:
+ *     rt_render(ctx, f, 1, 1); rt_display_rgba8_begin(ctx, f % 3, buf[f % 3], bytes);
+ *     if (f >= 2) { rt_display_rgba8_end(ctx, (f - 2) % 3); present(buf[(f - 2) % 3]); }                */
+int rt_display_rgba8_begin(rt_ctx *ctx, int slot, uint8_t *rgba8, size_t bytes);
+int rt_display_rgba8_end(rt_ctx *ctx, int slot);
+
 /* Checkpoint/resume of the progressive state (no reference counterpart: the reference keeps
  * it only in two GPU textures and m_frameCount, src/RayTracer.h:24-27): uploads a sum buffer
  * previously obtained from rt_readback together with its frame count. */

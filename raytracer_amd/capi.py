@@ -14,6 +14,7 @@ _LIB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib")
 
 RT_SLOT_OBJECTS, RT_SLOT_MATERIALS, RT_SLOT_MODEL_INFO, RT_SLOT_MODELS, RT_SLOT_TEXTURES = 1, 2, 3, 4, 5
 RT_TYPE_RGB, RT_TYPE_SPECTRAL = 0, 1
+RT_OK, RT_ERR_INVALID, RT_ERR_STATE, RT_ERR_HIP, RT_ERR_NO_DEVICE, RT_ERR_SCENE, RT_ERR_NOMEM = 0, -1, -2, -3, -4, -5, -6
 RT_OPT_SHADOW_EARLY_OUT, RT_OPT_REFILL_LANES, RT_OPT_INNER_SHARE, RT_OPT_MAX_PATHS, RT_OPT_TILE_MAJOR, RT_OPT_SPECTRAL_PDF_AS_WRITTEN = 1, 2, 3, 4, 5, 6
 RT_OPT_WIDE_BVH = 7
 RT_OPT_HERO_WAVELENGTH = 8
@@ -24,7 +25,7 @@ RT_OPT_PIPELINE = 11
 # Every symbol include/rt_hip.h declares.
 HIP_SYMBOLS = [
     "rt_create", "rt_destroy", "rt_upload", "rt_commit_scene", "rt_resize", "rt_set_frame", "rt_render", "rt_reserve",
-    "rt_reset_accum", "rt_sync", "rt_readback", "rt_display_rgba8", "rt_display_rgba8_noalloc", "rt_restore_accum", "rt_accum_device_ptr", "rt_bind_accum", "rt_add_frames",
+    "rt_reset_accum", "rt_sync", "rt_readback", "rt_display_rgba8", "rt_display_rgba8_noalloc", "rt_display_rgba8_begin", "rt_display_rgba8_end", "rt_restore_accum", "rt_accum_device_ptr", "rt_bind_accum", "rt_add_frames",
     "rt_trace_primary", "rt_eval_colour", "rt_get_stats", "rt_reset_stats", "rt_set_counters", "rt_set_option", "rt_set_tile_shard", "rt_strerror", "rt_last_hip_error",
     "rt_comm_unique_id", "rt_comm_init", "rt_reduce",
 ]
@@ -100,6 +101,8 @@ hip.rt_sync.argtypes = [_vp]
 hip.rt_readback.argtypes = [_vp, _vp, _sz, C.POINTER(_u32)]
 hip.rt_display_rgba8.argtypes = [_vp, _vp, _sz]
 hip.rt_display_rgba8_noalloc.argtypes = [_vp, _vp, _sz]
+hip.rt_display_rgba8_begin.argtypes = [_vp, _i, _vp, _sz]
+hip.rt_display_rgba8_end.argtypes = [_vp, _i]
 hip.rt_restore_accum.argtypes = [_vp, _vp, _sz, _u32]
 hip.rt_accum_device_ptr.argtypes = [_vp, C.POINTER(_vp), C.POINTER(_sz)]
 hip.rt_bind_accum.argtypes = [_vp, _vp, _sz]
@@ -272,6 +275,14 @@ class Backend:
         out = np.empty((self.height, self.width, 4), dtype=np.uint8)
         self._check(hip.rt_display_rgba8_noalloc(self._ctx, out.ctypes.data_as(_vp), out.size))
         return out
+
+    def display_begin(self, slot, ptr, nbytes):
+        """Queues the display pass and its copy to `ptr` (pinned host or device memory of H*W*4 bytes) and returns."""
+        self._check(hip.rt_display_rgba8_begin(self._ctx, slot, _vp(ptr), nbytes))
+
+    def display_end(self, slot):
+        """Blocks until the buffer given to the slot's last display_begin holds the frame."""
+        self._check(hip.rt_display_rgba8_end(self._ctx, slot))
 
     def restore_accum(self, rgba_sum, frames):
         a = np.ascontiguousarray(rgba_sum, dtype=np.float32)

@@ -148,6 +148,19 @@ struct rt_ctx {
     Pipe pipes[kPipes - 1];
     hipEvent_t fence = nullptr;        // pipe 0's
     hipEvent_t accumFence = nullptr;   // null: nothing pending on the sum buffer
+    // Asynchronous screen pass (rt_display_rgba8_begin/_end).  The pass and its copy are queued on the stream
+    // of the latest render call: behind that frame, and ahead only of the call that comes round to the same
+    // stream again (a stream of its own would be one more than the process has hardware queues for).
+    struct DisplaySlot {
+        uchar4 *staging = nullptr;
+        size_t bytes = 0;
+        hipEvent_t readDone = nullptr;   // the pass has read the sum buffer
+        hipEvent_t copied = nullptr;     // the caller's buffer holds the frame
+        bool busy = false;
+    };
+    static constexpr int kDisplaySlots = 4;
+    DisplaySlot displaySlots[kDisplaySlots];
+    hipStream_t lastRenderStream = nullptr;   // null: the context's own
     int nextPipe = 0;
     bool pipelineOn = true;            // RT_OPT_PIPELINE / env RT_PIPELINE
     uint64_t pipelinePaths = 1u << 20; // calls of at most this many paths are pipelined (a 1280x720 frame; a call of 4 Mi paths fills the chip
@@ -1563,6 +1576,11 @@ void rt_destroy(rt_ctx *ctx) {
         if (pipe.fence) hipEventDestroy(pipe.fence);
     }
     if (ctx->fence) hipEventDestroy(ctx->fence);
+    for (rt_ctx::DisplaySlot &d : ctx->displaySlots) {
+        if (d.staging) hipFree(d.staging);
+        if (d.readDone) hipEventDestroy(d.readDone);
+        if (d.copied) hipEventDestroy(d.copied);
+    }
     for (float *p : ctx->dStream) if (p) hipFree(p);
     void *owned[] = {ctx->dNodes, ctx->dWNodes, ctx->dW8Nodes, ctx->dWPairs, ctx->pb.overflow, ctx->pb.retrace, ctx->dWTris, ctx->dTris, ctx->dShade, ctx->dModelDesc, ctx->accumExternal ? nullptr : (void *)ctx->dAccum, ctx->dPartial,
                      ctx->pb.rays, ctx->pb.hits, ctx->pb.stA, ctx->pb.stB, ctx->pb.neeA, ctx->pb.neeB, ctx->pb.neeC,
@@ -1837,6 +1855,7 @@ static int renderPlanes(rt_ctx *ctx, int pipeNo, uint64_t g0, uint64_t g1, uint3
     }
     if (e1) hipEventRecord(e1, ctx->stream);
     if (e0 && e1) ctx->renderEvents.push_back({e0, e1});
+    ctx->lastRenderStream = ctx->stream;   // (the pipe's, while the scope lasts)
     return RT_OK;
 }
 
@@ -1961,6 +1980,45 @@ int rt_display_rgba8_noalloc(rt_ctx *ctx, uint8_t *rgba8, size_t bytes) {
     hipLaunchKernelGGL(k_display, dim3(gridFor(ctx, px, 8)), dim3(kBlock), 0, ctx->stream, ctx->dAccum, ctx->displayScratch, (uint32_t)px);
     RT_HIP(hipMemcpyAsync(rgba8, ctx->displayScratch, bytes, hipMemcpyDefault, ctx->stream));
     RT_HIP(hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+int rt_display_rgba8_begin(rt_ctx *ctx, int slot, uint8_t *rgba8, size_t bytes) {
+    if (ctx == nullptr || rgba8 == nullptr || slot < 0 || slot >= rt_ctx::kDisplaySlots) return RT_ERR_INVALID;
+    if (ctx->dAccum == nullptr) return RT_ERR_STATE;
+    const size_t px = (size_t)ctx->W * ctx->H;
+    if (bytes != px * 4) return RT_ERR_INVALID;
+    rt_ctx::DisplaySlot &d = ctx->displaySlots[slot];
+    if (d.busy) return RT_ERR_STATE;   // begun and not ended
+    RT_HIP(hipSetDevice(ctx->device));
+    const hipStream_t stream = ctx->lastRenderStream != nullptr ? ctx->lastRenderStream : ctx->stream;
+    if (d.readDone == nullptr) RT_HIP(hipEventCreateWithFlags(&d.readDone, hipEventDisableTiming));
+    if (d.copied == nullptr) RT_HIP(hipEventCreateWithFlags(&d.copied, hipEventDisableTiming));
+    if (d.bytes != bytes) {   // first use of the slot at this resolution (rt_display_rgba8_end has waited for its last frame)
+        d.bytes = 0;
+        int rc = devAlloc(ctx, &d.staging, px);
+        if (rc != RT_OK) return rc;
+        d.bytes = bytes;
+    }
+    // The pass takes its place behind everything queued so far that touches the sum buffer, and what is
+    // queued afterwards waits until the pass has read it.
+    if (ctx->accumFence != nullptr) RT_HIP(hipStreamWaitEvent(stream, ctx->accumFence, 0));
+    hipLaunchKernelGGL(k_display, dim3(gridFor(ctx, px, 8)), dim3(kBlock), 0, stream, ctx->dAccum, d.staging, (uint32_t)px);
+    RT_HIP(hipEventRecord(d.readDone, stream));
+    ctx->accumFence = d.readDone;
+    RT_HIP(hipMemcpyAsync(rgba8, d.staging, bytes, hipMemcpyDefault, stream));
+    RT_HIP(hipEventRecord(d.copied, stream));
+    d.busy = true;
+    return RT_OK;
+}
+
+int rt_display_rgba8_end(rt_ctx *ctx, int slot) {
+    if (ctx == nullptr || slot < 0 || slot >= rt_ctx::kDisplaySlots) return RT_ERR_INVALID;
+    rt_ctx::DisplaySlot &d = ctx->displaySlots[slot];
+    if (!d.busy) return RT_ERR_STATE;
+    RT_HIP(hipSetDevice(ctx->device));
+    d.busy = false;
+    RT_HIP(hipEventSynchronize(d.copied));
     return RT_OK;
 }
 

@@ -110,3 +110,76 @@ def test_reserve_prepares_every_stream_of_the_pipeline():
         finally:
             b.close()
     assert np.array_equal(images[0].view(np.uint32), images[1].view(np.uint32))
+
+
+def test_display_without_the_wait_shows_each_frame_as_the_waiting_call_does():
+    """rt_display_rgba8_begin/_end after every one-frame call, two and three frames in flight, against
+    rt_display_rgba8 after the same frames: every displayed frame and the final sum buffer are the same."""
+    import torch
+
+    W, H, frames = 320, 200, 12
+    scene = capi.Scene("cornell_knot", nu=256, nv=32)
+    cam = capi.make_camera(width=W, height=H, bounces=4, ray_per_pixel=1)
+    b = _backend(scene, W, H, cam, capi.RT_TYPE_RGB, False)
+    try:
+        want = []
+        for f in range(frames):
+            b.render(1 + f, 1, 1)
+            want.append(b.display_rgba8())
+        want_sum, _ = b.readback()
+    finally:
+        b.close()
+    for in_flight in (2, 3):
+        b = _backend(scene, W, H, cam, capi.RT_TYPE_RGB, True)
+        try:
+            bufs = [torch.empty((H, W, 4), dtype=torch.uint8).pin_memory() for _ in range(in_flight)]
+            got = []
+            for f in range(frames):
+                b.render(1 + f, 1, 1)
+                slot = f % in_flight
+                b.display_begin(slot, bufs[slot].data_ptr(), bufs[slot].numel())
+                if f >= in_flight - 1:
+                    done = (f - (in_flight - 1)) % in_flight
+                    b.display_end(done)
+                    got.append(bufs[done].numpy().copy())
+            for f in range(frames - (in_flight - 1), frames):
+                b.display_end(f % in_flight)
+                got.append(bufs[f % in_flight].numpy().copy())
+            got_sum, n = b.readback()
+            assert n == frames
+        finally:
+            b.close()
+        assert len(got) == frames
+        for f in range(frames):
+            assert np.array_equal(got[f], want[f]), f"frame {f}, {in_flight} in flight"
+        assert np.array_equal(got_sum.view(np.uint32), want_sum.view(np.uint32))
+
+
+def test_display_slots_refuse_misuse():
+    import ctypes as C
+
+    W, H = 64, 48
+    scene = capi.Scene("cornell_knot", nu=32, nv=8)
+    cam = capi.make_camera(width=W, height=H, bounces=2, ray_per_pixel=1)
+    b = _backend(scene, W, H, cam, capi.RT_TYPE_RGB, True)
+    try:
+        b.render(1, 1, 1)
+        out = np.empty((H, W, 4), dtype=np.uint8)
+        ptr, n = out.ctypes.data_as(C.c_void_p), out.size
+        assert capi.hip.rt_display_rgba8_end(b._ctx, 0) == capi.RT_ERR_STATE        # nothing begun
+        assert capi.hip.rt_display_rgba8_begin(b._ctx, 4, ptr, n) == capi.RT_ERR_INVALID   # no such slot
+        assert capi.hip.rt_display_rgba8_begin(b._ctx, 0, ptr, 16) == capi.RT_ERR_INVALID  # wrong size
+        assert capi.hip.rt_display_rgba8_begin(b._ctx, 0, ptr, n) == capi.RT_OK          # pageable memory works, it only waits
+        assert capi.hip.rt_display_rgba8_begin(b._ctx, 0, ptr, n) == capi.RT_ERR_STATE   # begun twice
+        assert capi.hip.rt_display_rgba8_end(b._ctx, 0) == capi.RT_OK
+        assert np.array_equal(out, b.display_rgba8())
+        b.resize(W * 2, H)                                                               # the slot follows the new size
+        cam2 = capi.make_camera(width=W * 2, height=H, bounces=2, ray_per_pixel=1)
+        b.set_frame(cam2, scene.sky, capi.RT_TYPE_RGB)
+        b.render(1, 1, 1)
+        out2 = np.empty((H, W * 2, 4), dtype=np.uint8)
+        assert capi.hip.rt_display_rgba8_begin(b._ctx, 0, out2.ctypes.data_as(C.c_void_p), out2.size) == capi.RT_OK
+        assert capi.hip.rt_display_rgba8_end(b._ctx, 0) == capi.RT_OK
+        assert np.array_equal(out2, b.display_rgba8())
+    finally:
+        b.close()
