@@ -381,6 +381,35 @@ def one_frame_per_call(scene, rtype, device):
                 out["mrays_per_s"] = round(be.stats()["rays"] / dt / 1e6, 1)
         finally:
             be.close()
+    # ... and with every frame tonemapped and copied to the host, as the reference's loop shows every frame:
+    # the display call that waits, and the begin/end pair with three frames in flight.
+    import torch
+    bufs = [torch.empty((540, 960, 4), dtype=torch.uint8).pin_memory() for _ in range(3)]
+    for key, split in (("frames_per_s_every_frame_displayed", True), ("frames_per_s_every_frame_displayed_waiting_call", False)):
+        be = capi.Backend(device)
+        try:
+            be.upload_scene(scene)
+            be.resize(960, 540)
+            be.set_frame(cam, scene.sky, rtype)
+            for f in range(6):
+                be.render(first_frame=1 + f, n_frames=1, stride=1)
+            be.display_rgba8_noalloc()
+            t0 = time.perf_counter()
+            for f in range(300):
+                be.render(first_frame=7 + f, n_frames=1, stride=1)
+                if split:
+                    be.display_begin(f % 3, bufs[f % 3].data_ptr(), bufs[f % 3].numel())
+                    if f >= 2:
+                        be.display_end((f - 2) % 3)
+                else:
+                    be.display_rgba8_noalloc()
+            if split:
+                be.display_end(298 % 3)
+                be.display_end(299 % 3)
+            be.sync()
+            out[key] = round(300 / (time.perf_counter() - t0), 1)
+        finally:
+            be.close()
     return out
 
 
