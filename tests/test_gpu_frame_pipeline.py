@@ -173,6 +173,12 @@ def test_display_slots_refuse_misuse():
         assert capi.hip.rt_display_rgba8_begin(b._ctx, 0, ptr, n) == capi.RT_ERR_STATE   # begun twice
         assert capi.hip.rt_display_rgba8_end(b._ctx, 0) == capi.RT_OK
         assert np.array_equal(out, b.display_rgba8())
+        import torch
+        dev = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda:0")                 # device memory as the destination
+        torch.cuda.synchronize()
+        assert capi.hip.rt_display_rgba8_begin(b._ctx, 1, C.c_void_p(dev.data_ptr()), dev.numel()) == capi.RT_OK
+        assert capi.hip.rt_display_rgba8_end(b._ctx, 1) == capi.RT_OK
+        assert np.array_equal(dev.cpu().numpy(), out)
         b.resize(W * 2, H)                                                               # the slot follows the new size
         cam2 = capi.make_camera(width=W * 2, height=H, bounces=2, ray_per_pixel=1)
         b.set_frame(cam2, scene.sky, capi.RT_TYPE_RGB)
