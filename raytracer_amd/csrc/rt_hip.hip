@@ -1124,7 +1124,7 @@ int buildWide8(rt_ctx *ctx, std::vector<ModelDesc> &descs, std::vector<Wide8Node
             fam.kids[bs] = kids[bi];
         }
         Wide8Node wn{};
-        uint32_t imask = 0, innerCount = 0, triCount = 0;
+        uint32_t imask = 0, triCount = 0;
         uint8_t meta[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         const uint32_t triBase = (uint32_t)w8tris.size();
         for (int sl = 0; sl < 8; ++sl) {
@@ -1138,7 +1138,6 @@ int buildWide8(rt_ctx *ctx, std::vector<ModelDesc> &descs, std::vector<Wide8Node
             } else {
                 meta[sl] = (uint8_t)(0x38u + (uint32_t)sl);   // one bit, at place 24 + slot
                 imask |= 1u << sl;
-                innerCount++;
             }
         }
         wn.childBase = (uint32_t)w8.size();
