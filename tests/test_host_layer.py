@@ -199,3 +199,27 @@ def test_sah_trees_render_the_same_image_with_fewer_visits():
     assert differing <= 2                                   # exact-tie pixels only, if any
     assert out["sah"][1]["node_visits"] < 0.85 * out["reference"][1]["node_visits"]
     assert out["sah"][1]["rays"] in range(out["reference"][1]["rays"] - 8, out["reference"][1]["rays"] + 9)
+
+
+def test_headers_compile_as_c99_and_link_from_c(tmp_path):
+    """The boundary is a C ABI: both public headers must be plain C, and a C program must link against the libraries."""
+    import shutil
+    import subprocess
+
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "abi.c"
+    src.write_text(
+        "#include <stddef.h>\n#include <stdint.h>\n#include \"rt_hip.h\"\n#include \"rt_host.h\"\n"
+        "int main(void) {\n"
+        "    rt_ctx *ctx = NULL;\n"
+        "    int rc = rt_create(&ctx, 0);\n"
+        "    if (rc == RT_OK) { rc = rt_display_rgba8_end(ctx, 0) == RT_ERR_STATE ? RT_OK : 1; rt_destroy(ctx); return rc; }\n"
+        "    return rc == RT_ERR_NO_DEVICE ? 0 : 1;   /* no GPU: refused, nothing else */\n"
+        "}\n")
+    lib = os.path.join(ROOT, "raytracer_amd", "lib")
+    exe = tmp_path / "abi"
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                    "-L", lib, "-lrt_host", "-lrt_hip", "-Wl,-rpath," + lib], check=True)
+    assert subprocess.run([str(exe)]).returncode == 0
