@@ -324,6 +324,11 @@ __global__ __launch_bounds__(kBlock, COUNT ? kCountingWaves : WIDE ? ((ALPHA && 
         return false;
     };
     auto modelHasHit = [&]() -> bool { return kWriteThrough ? r.model < 0 : r.mBest != kMiss; };
+    auto writeMiss = [&]() {
+        HitRec rec;
+        rec.t = 1e20f; rec.u = 0.0f; rec.v = 0.0f; rec.id = kMiss;
+        *reinterpret_cast<float4 *>(&pb.hits[r.slot]) = *reinterpret_cast<const float4 *>(&rec);
+    };
     // Records an accepted hit: in the lane, or (write-through instances) in the ray's hit record at once.
     auto acceptHit = [&](float t, float u, float v, uint32_t tri) {   // (tri by value: the no-texture mark is added to the copy)
         r.maxT = t;
@@ -494,10 +499,10 @@ __global__ __launch_bounds__(kBlock, COUNT ? kCountingWaves : WIDE ? ((ALPHA && 
                         // hit need not be carried in registers.
                         r.closest = 1e20f;
                         if (kWriteThrough) r.maxT = 1e20f;   // one distance for the whole ray: it only ever shrinks
-                        HitRec rec;
-                        rec.t = 1e20f; rec.u = 0.0f; rec.v = 0.0f; rec.id = kMiss;
-                        *reinterpret_cast<float4 *>(&pb.hits[r.slot]) = *reinterpret_cast<const float4 *>(&rec);
                         active = enterModel<WIDE, kWriteThrough>(sc, rootLds, r, 0);
+                        // Write-through instances write the miss record when the ray ENDS without a hit (most rays hit
+                        // something, and their first accepted triangle would overwrite it); the others now.
+                        if (!kWriteThrough || !active) writeMiss();
                     }
                 }
             }
@@ -633,6 +638,8 @@ __global__ __launch_bounds__(kBlock, COUNT ? kCountingWaves : WIDE ? ((ALPHA && 
                         rec.t = r.closest; rec.u = r.bestU; rec.v = r.bestV; rec.id = id;
                         *reinterpret_cast<float4 *>(&pb.hits[r.slot]) = *reinterpret_cast<const float4 *>(&rec);
                     }
+                    // (no hit in any model: every distance the wide build admits is far below the initial 1e20)
+                    if (kWriteThrough && !PRIMS && r.maxT == 1e20f) writeMiss();
                     if (WIDE && hasTie(r) && pb.retrace != nullptr) {
                         // Two triangles of one model at the closest distance: the reference's winner is
                         // the one ITS walk meets first, so this ray is traced again in that order.
