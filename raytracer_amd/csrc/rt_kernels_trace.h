@@ -480,11 +480,15 @@ __global__ __launch_bounds__(kBlock, COUNT ? kCountingWaves : WIDE ? ((ALPHA && 
                     r.tStop = WIDE ? (r1.w > 0.0f ? r1.w : 0.0f) : r1.w;
                     if (PRIMS && kWriteThrough) {
                         intersectPrimitives<COUNT>(sc, r, cntTris);
-                        HitRec rec;    // the primitives' answer; accepted triangles overwrite it
-                        rec.t = r.closest; rec.u = r.bestU; rec.v = r.bestV; rec.id = r.bestId;
-                        *reinterpret_cast<float4 *>(&pb.hits[r.slot]) = *reinterpret_cast<const float4 *>(&rec);
                         r.maxT = r.closest;
                         active = !(r.closest < r.tStop) && enterModel<WIDE, true>(sc, rootLds, r, 0);
+                        if (r.bestId != kMiss) {   // the primitives' answer; accepted triangles overwrite it
+                            HitRec rec;
+                            rec.t = r.closest; rec.u = r.bestU; rec.v = r.bestV; rec.id = r.bestId;
+                            *reinterpret_cast<float4 *>(&pb.hits[r.slot]) = *reinterpret_cast<const float4 *>(&rec);
+                        } else if (!active) {      // (a ray that goes on writes its miss record when it ends without a hit)
+                            writeMiss();
+                        }
                     } else if (PRIMS) {
                         intersectPrimitives<COUNT>(sc, r, cntTris);
                         active = !(r.closest < r.tStop) && enterModel<WIDE>(sc, rootLds, r, 0);
@@ -639,7 +643,7 @@ __global__ __launch_bounds__(kBlock, COUNT ? kCountingWaves : WIDE ? ((ALPHA && 
                         *reinterpret_cast<float4 *>(&pb.hits[r.slot]) = *reinterpret_cast<const float4 *>(&rec);
                     }
                     // (no hit in any model: every distance the wide build admits is far below the initial 1e20)
-                    if (kWriteThrough && !PRIMS && r.maxT == 1e20f) writeMiss();
+                    if (kWriteThrough && r.maxT == 1e20f) writeMiss();
                     if (WIDE && hasTie(r) && pb.retrace != nullptr) {
                         // Two triangles of one model at the closest distance: the reference's winner is
                         // the one ITS walk meets first, so this ray is traced again in that order.
