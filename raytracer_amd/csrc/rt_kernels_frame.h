@@ -81,7 +81,7 @@ __global__ __launch_bounds__(kBlock) void k_generate(FrameParams fp, Batch bt, P
                     pb.stA[p] = make_float4(1.0f, 1.0f, lambda, 0.0f);
                     pb.stB[p] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(seed));
                 } else {
-                    pb.stA[p] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+                    // (RGB: throughput and previous pdf start at one; k_shade_rgb knows that at stage 0 and does not read them)
                     pb.stB[p] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(seed));
                 }
             }

@@ -130,7 +130,8 @@ __global__ __launch_bounds__(kBlock, RT_SHADE_BLOCKS) void k_shade_rgb(SceneView
             path = qIn[i];
             const RayRec ray = pb.rays[path];
             const HitRec h = pb.hits[path];
-            const float4 sA = pb.stA[path];
+            // A camera path starts with throughput and previous pdf one: k_generate does not store them.
+            const float4 sA = stage == 0 ? make_float4(1.0f, 1.0f, 1.0f, 1.0f) : pb.stA[path];
             float4 sB = pb.stB[path];
             V3 rayColor = v3(sA.x, sA.y, sA.z);
             float prevBrdfPdf = sA.w;
