@@ -60,7 +60,7 @@ __global__ __launch_bounds__(kBlock) void k_generate(FrameParams fp, Batch bt, P
                 d = normalize(d - fp.position);
 
                 RayRec r;
-                r.ox = fp.position.x; r.oy = fp.position.y; r.oz = fp.position.z; r.pad0 = 0.0f;
+                r.ox = fp.position.x; r.oy = fp.position.y; r.oz = fp.position.z; r.pad0 = SPECTRAL ? 0.0f : __uint_as_float(seed);   // (RGB: below)
                 r.dx = d.x; r.dy = d.y; r.dz = d.z; r.pad1 = kNeverStop;
                 pb.rays[p] = r;
                 if (SPECTRAL && heroPass >= 0) {
@@ -81,8 +81,8 @@ __global__ __launch_bounds__(kBlock) void k_generate(FrameParams fp, Batch bt, P
                     pb.stA[p] = make_float4(1.0f, 1.0f, lambda, 0.0f);
                     pb.stB[p] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(seed));
                 } else {
-                    // (RGB: throughput and previous pdf start at one; k_shade_rgb knows that at stage 0 and does not read them)
-                    pb.stB[p] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(seed));
+                    // RGB: throughput and previous pdf start at one and the radiance at zero, which k_shade_rgb knows at
+                    // stage 0; the path's random state travels in the unused word of its ray record (above).
                 }
             }
         }

@@ -132,7 +132,7 @@ __global__ __launch_bounds__(kBlock, RT_SHADE_BLOCKS) void k_shade_rgb(SceneView
             const HitRec h = pb.hits[path];
             // A camera path starts with throughput and previous pdf one: k_generate does not store them.
             const float4 sA = stage == 0 ? make_float4(1.0f, 1.0f, 1.0f, 1.0f) : pb.stA[path];
-            float4 sB = pb.stB[path];
+            float4 sB = stage == 0 ? make_float4(0.0f, 0.0f, 0.0f, ray.pad0) : pb.stB[path];   // (a camera ray carries the seed)
             V3 rayColor = v3(sA.x, sA.y, sA.z);
             float prevBrdfPdf = sA.w;
             V3 incoming = v3(sB.x, sB.y, sB.z);
@@ -275,6 +275,10 @@ __global__ __launch_bounds__(kBlock, RT_SHADE_BLOCKS) void k_shade_rgb(SceneView
                         pb.stA[path] = make_float4(rayColor.x, rayColor.y, rayColor.z, prevBrdfPdf);
                         pb.stB[path] = make_float4(incoming.x, incoming.y, incoming.z, __uint_as_float(seed));
                         wantExt = true;
+                    } else if (stage == 0) {
+                        // A path that ends at its first hit: nobody has written its radiance record yet, and
+                        // k_connect and k_resolve read it.
+                        pb.stB[path] = make_float4(incoming.x, incoming.y, incoming.z, __uint_as_float(seed));
                     }
                 }
             }
