@@ -59,10 +59,9 @@ __global__ __launch_bounds__(kBlock) void k_generate(FrameParams fp, Batch bt, P
                 if (!SPECTRAL && !fp.stratified) d = uv + jx * fp.rImgX * fp.right + jy * fp.rImgY * fp.up;   // :589
                 d = normalize(d - fp.position);
 
-                RayRec r;
-                r.ox = fp.position.x; r.oy = fp.position.y; r.oz = fp.position.z; r.pad0 = SPECTRAL ? 0.0f : __uint_as_float(seed);   // (RGB: below)
-                r.dx = d.x; r.dy = d.y; r.dz = d.z; r.pad1 = kNeverStop;
-                pb.rays[p] = r;
+                // Throughput and previous pdf start at one and the radiance at zero, which the shading kernels know
+                // at stage 0: only the wavelength is stored (Spectral), and the path's random state travels in the
+                // unused word of its ray record.
                 if (SPECTRAL && heroPass >= 0) {
                     // The seed is passed to traceColorWavelength by value (src/RayTracer.cpp:1051), so
                     // every wavelength of the sample starts from the same state: the one after this draw.
@@ -75,15 +74,14 @@ __global__ __launch_bounds__(kBlock) void k_generate(FrameParams fp, Batch bt, P
                     }
                     pb.neeC[p] = sum;
                     pb.stA[p] = make_float4(1.0f, 1.0f, heroWavelength(heroPass, baseOffset), 0.0f);
-                    pb.stB[p] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(seed));
                 } else if (SPECTRAL) {
                     float lambda = (rand_float(seed) + (float)(i * fp.ssq) + (float)j) * fp.wlDt + kWlMin;
                     pb.stA[p] = make_float4(1.0f, 1.0f, lambda, 0.0f);
-                    pb.stB[p] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(seed));
-                } else {
-                    // RGB: throughput and previous pdf start at one and the radiance at zero, which k_shade_rgb knows at
-                    // stage 0; the path's random state travels in the unused word of its ray record (above).
                 }
+                RayRec r;
+                r.ox = fp.position.x; r.oy = fp.position.y; r.oz = fp.position.z; r.pad0 = __uint_as_float(seed);
+                r.dx = d.x; r.dy = d.y; r.dz = d.z; r.pad1 = kNeverStop;
+                pb.rays[p] = r;
             }
         }
         const uint32_t sub = blockIdx.x % kSubQueues;

@@ -310,7 +310,7 @@ __global__ __launch_bounds__(kBlock) void k_shade_spectral(SceneView sc, FramePa
             const RayRec ray = pb.rays[path];
             const HitRec h = pb.hits[path];
             const float4 sA = pb.stA[path];
-            float4 sB = pb.stB[path];
+            float4 sB = stage == 0 ? make_float4(0.0f, 0.0f, 0.0f, ray.pad0) : pb.stB[path];   // (a camera ray carries the seed)
             float throughput = sA.x, prevBrdfPdf = sA.y;
             const float lambda = sA.z;
             float radiance = sB.x;
@@ -462,6 +462,12 @@ __global__ __launch_bounds__(kBlock) void k_shade_spectral(SceneView sc, FramePa
                         sB.w = __uint_as_float(seed);
                         pb.stB[path] = sB;
                         wantExt = true;
+                    } else if (stage == 0) {
+                        // A path that ends at its first hit: nobody has written its radiance record yet, and
+                        // k_connect, k_resolve and the next hero-wavelength pass read it.
+                        sB.x = radiance;
+                        sB.w = __uint_as_float(seed);
+                        pb.stB[path] = sB;
                     }
                 }
             }
