@@ -413,12 +413,12 @@ def one_frame_per_call(scene, rtype, device):
     return out
 
 
-LIMITS_PROFILE = "profiles/r02_h_limits.json"
+LIMITS_PROFILE = "profiles/r02_i_limits.json"
 
 
 def measured_limits(args):
     """What rocprofv3's counters say about the traversal kernel of this same command (tools/roofline_limits.sh
-    + tools/roofline_report.py -> profiles/r02_h_limits.json).  Counters cannot be read from inside this
+    + tools/roofline_report.py -> profiles/r02_i_limits.json).  Counters cannot be read from inside this
     process, so the figures are the ones measured on this command; they are only reported for the default
     workload they were measured on."""
     path = os.path.join(ROOT, LIMITS_PROFILE)
