@@ -72,16 +72,26 @@ struct __attribute__((aligned(16))) TriPair {
     float acz[2]; int32_t ident[2];   // index into tris (what hit records carry)
 };
 static_assert(sizeof(TriPair) == 80, "triangle pair must be five 16-byte pieces");
-// What shading needs of a triangle besides PackedTri, under the same index: the vertex normals and
-// texture coordinates gathered from the vertex stream at commit time.  A hit then costs two
-// independent fetches (112 contiguous bytes) instead of the chain triangle -> identifier -> three
-// vertices.
+// What shading needs of a triangle whose material has no textures, in one 64-byte line under the
+// triangle's index: the vertex normals gathered from the vertex stream at commit time, and what
+// resolveHit would otherwise derive from PackedTri on every hit -- cross(B - A, C - A), the area
+// (0.5 * length of that, src/RayScene.cpp:677-679), material and model -- computed at commit with the
+// same correctly rounded operations.  A textured triangle also reads its PackedTri and PackedUV.
 struct __attribute__((aligned(64))) PackedShade {
     float n0[3], n1[3], n2[3];
-    float uv0[2], uv1[2], uv2[2];
+    float geometric[3];          // cross(ab, ac)
+    float area;
+    int32_t material;            // scene-wide material index
+    int32_t model;               // model slot
     int32_t hasTextures;         // the identifier's texture flag (src/RayScene.cpp:659)
 };
 static_assert(sizeof(PackedShade) == 64, "shading record must be one 64-byte line");
+// Texture coordinates of the three vertices (textured triangles and the alpha-cut test only).
+struct __attribute__((aligned(32))) PackedUV {
+    float uv0[2], uv1[2], uv2[2];
+    float pad[2];
+};
+static_assert(sizeof(PackedUV) == 32, "texture coordinates must be half a 64-byte line");
 
 constexpr int32_t kTriAlphaTest = 1 << 30;  // triangle needs the alpha-cut texture test
 constexpr int32_t kTriModelMask = (1 << 30) - 1;
@@ -105,6 +115,7 @@ struct SceneView {
     const Wide8Node *w8nodes;   // eight-wide tree, null unless that mode is on
     const PackedTri *tris;
     const PackedShade *shade;   // [triangle], same index as tris
+    const PackedUV *uvs;        // [triangle], same index as tris
     const PackedTri *wtris;     // four-wide trees: the triangles in THEIR leaf order; `ident` holds the index into tris
     const TriPair *wpairs;      // four-wide trees of scenes without alpha-cut textures: the leaves as triangle pairs (leaf references then count pairs)
     const ModelDesc *modelDesc;
@@ -347,24 +358,24 @@ RT_FN HitInfoD resolveHit(const SceneView &sc, V3 ro, V3 rd, const HitRec &h) {
         return info;
     }
 
-    const PackedTri &pt = sc.tris[h.id & kIndexMask];
-    const PackedShade &ps = sc.shade[h.id & kIndexMask];
-    const ModelDesc &md = sc.modelDesc[pt.model & kTriModelMask];
-    const int materialIndex = pt.material;
+    const uint32_t tri = h.id & kIndexMask;
+    const PackedShade &ps = sc.shade[tri];
+    const ModelDesc &md = sc.modelDesc[ps.model];
     const bool hasTextures = ps.hasTextures != 0;
-    const V3 vertexA = v3(pt.a[0], pt.a[1], pt.a[2]);
-    const V3 edgeAB = v3(pt.ab[0], pt.ab[1], pt.ab[2]), edgeAC = v3(pt.ac[0], pt.ac[1], pt.ac[2]);
     const V3 n0 = v3(ps.n0[0], ps.n0[1], ps.n0[2]), n1 = v3(ps.n1[0], ps.n1[1], ps.n1[2]), n2 = v3(ps.n2[0], ps.n2[1], ps.n2[2]);
-    const V2 uv0 = v2(ps.uv0[0], ps.uv0[1]), uv1 = v2(ps.uv1[0], ps.uv1[1]), uv2 = v2(ps.uv2[0], ps.uv2[1]);
 
-    V3 geometric = cross(edgeAB, edgeAC);
-    info.normal = triangleNormal(n0, n1, n2, geometric, h.u, h.v);
+    info.normal = triangleNormal(n0, n1, n2, v3(ps.geometric[0], ps.geometric[1], ps.geometric[2]), h.u, h.v);
     info.front_face = dot(rd, info.normal) < 0.0f;
-    info.area = 0.5f * length(geometric);                       // triArea, src/RayScene.cpp:677-679
+    info.area = ps.area;                                        // triArea, src/RayScene.cpp:677-679
     info.modelLightCounts = md.lightSourcesCount;
-    info.mat = loadMaterial(sc, materialIndex);
+    info.mat = loadMaterial(sc, ps.material);
 
-    if (hasTextures && (h.id & kNoTexBit) == 0u) applyTextures(sc, info, rd, vertexA, edgeAB, edgeAC, uv0, uv1, uv2);   // src/RayScene.cpp:763
+    if (hasTextures && (h.id & kNoTexBit) == 0u) {              // src/RayScene.cpp:763
+        const PackedTri &pt = sc.tris[tri];
+        const PackedUV &pu = sc.uvs[tri];
+        applyTextures(sc, info, rd, v3(pt.a[0], pt.a[1], pt.a[2]), v3(pt.ab[0], pt.ab[1], pt.ab[2]), v3(pt.ac[0], pt.ac[1], pt.ac[2]),
+                      v2(pu.uv0[0], pu.uv0[1]), v2(pu.uv1[0], pu.uv1[1]), v2(pu.uv2[0], pu.uv2[1]));
+    }
     return info;
 }
 

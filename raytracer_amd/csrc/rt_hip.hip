@@ -91,6 +91,7 @@ struct rt_ctx {
     uint32_t overflowWords = 0;     // 4-byte words per lane allocated in pb.overflow
     PackedTri *dTris = nullptr;
     PackedShade *dShade = nullptr;
+    PackedUV *dUVs = nullptr;
     ModelDesc *dModelDesc = nullptr;
     std::vector<PackedTri> hTris;   // kept for id decoding in rt_trace_primary
     SceneView view{};
@@ -288,7 +289,7 @@ int gridFor(const rt_ctx *ctx, uint64_t items, int blocksPerCU) {
 
 // Builds the traversal re-pack from the uploaded model streams and validates
 // every offset the kernels will follow.
-int repackScene(rt_ctx *ctx, std::vector<PackedNode> &nodes, std::vector<PackedTri> &tris, std::vector<PackedShade> &shade, std::vector<ModelDesc> &descs) {
+int repackScene(rt_ctx *ctx, std::vector<PackedNode> &nodes, std::vector<PackedTri> &tris, std::vector<PackedShade> &shade, std::vector<PackedUV> &uvs, std::vector<ModelDesc> &descs) {
     const std::vector<float> &info = ctx->host[RT_SLOT_MODEL_INFO];
     const std::vector<float> &mdl = ctx->host[RT_SLOT_MODELS];
     const std::vector<float> &mats = ctx->host[RT_SLOT_MATERIALS];
@@ -397,13 +398,21 @@ int repackScene(rt_ctx *ctx, std::vector<PackedNode> &nodes, std::vector<PackedT
                 ps.n1[k] = B[3 + k];
                 ps.n2[k] = C[3 + k];
             }
-            for (int k = 0; k < 2; ++k) {
-                ps.uv0[k] = A[6 + k];
-                ps.uv1[k] = B[6 + k];
-                ps.uv2[k] = C[6 + k];
-            }
+            // (the same single-precision operations, in the same order, as the kernels would run on every hit)
+            const V3 geometric = cross(v3(pt.ab[0], pt.ab[1], pt.ab[2]), v3(pt.ac[0], pt.ac[1], pt.ac[2]));
+            ps.geometric[0] = geometric.x; ps.geometric[1] = geometric.y; ps.geometric[2] = geometric.z;
+            ps.area = 0.5f * length(geometric);
+            ps.material = material;
+            ps.model = m;
             ps.hasTextures = hasTextures ? 1 : 0;
             shade.push_back(ps);
+            PackedUV pu{};
+            for (int k = 0; k < 2; ++k) {
+                pu.uv0[k] = A[6 + k];
+                pu.uv1[k] = B[6 + k];
+                pu.uv2[k] = C[6 + k];
+            }
+            uvs.push_back(pu);
         }
 
         // Inner nodes get consecutive packed indices in original node order.
@@ -1581,7 +1590,7 @@ void rt_destroy(rt_ctx *ctx) {
         if (d.copied) hipEventDestroy(d.copied);
     }
     for (float *p : ctx->dStream) if (p) hipFree(p);
-    void *owned[] = {ctx->dNodes, ctx->dWNodes, ctx->dW8Nodes, ctx->dWPairs, ctx->pb.overflow, ctx->pb.retrace, ctx->dWTris, ctx->dTris, ctx->dShade, ctx->dModelDesc, ctx->accumExternal ? nullptr : (void *)ctx->dAccum, ctx->dPartial,
+    void *owned[] = {ctx->dNodes, ctx->dWNodes, ctx->dW8Nodes, ctx->dWPairs, ctx->pb.overflow, ctx->pb.retrace, ctx->dWTris, ctx->dTris, ctx->dShade, ctx->dUVs, ctx->dModelDesc, ctx->accumExternal ? nullptr : (void *)ctx->dAccum, ctx->dPartial,
                      ctx->pb.rays, ctx->pb.hits, ctx->pb.stA, ctx->pb.stB, ctx->pb.neeA, ctx->pb.neeB, ctx->pb.neeC,
                      ctx->pb.qExt[0], ctx->pb.qExt[1], ctx->pb.qShadow, ctx->pb.stages, ctx->pb.counters};
     for (void *p : owned) if (p) hipFree(p);
@@ -1622,6 +1631,7 @@ static int commitScene(rt_ctx *ctx, int objectCount, int modelsCount, int lightS
     std::vector<PackedNode> nodes;
     std::vector<PackedTri> tris;
     std::vector<PackedShade> shade;
+    std::vector<PackedUV> uvs;
     std::vector<ModelDesc> descs;
     // RT_COMMIT_TIMING=1 prints where a commit spends its host time.
     const bool timing = std::getenv("RT_COMMIT_TIMING") != nullptr;
@@ -1632,7 +1642,7 @@ static int commitScene(rt_ctx *ctx, int objectCount, int modelsCount, int lightS
         since = now;
     };
     auto mark = clockNow();
-    int rc = repackScene(ctx, nodes, tris, shade, descs);
+    int rc = repackScene(ctx, nodes, tris, shade, uvs, descs);
     if (rc != RT_OK) return rc;
     lap("validate + re-pack", mark);
 
@@ -1692,6 +1702,8 @@ static int commitScene(rt_ctx *ctx, int objectCount, int modelsCount, int lightS
     if ((rc = devAlloc(ctx, &ctx->dTris, tris.size())) != RT_OK) return rc;
     if ((rc = devAlloc(ctx, &ctx->dShade, shade.size())) != RT_OK) return rc;
     if (!shade.empty()) RT_HIP(hipMemcpy(ctx->dShade, shade.data(), shade.size() * sizeof(PackedShade), hipMemcpyHostToDevice));
+    if ((rc = devAlloc(ctx, &ctx->dUVs, uvs.size())) != RT_OK) return rc;
+    if (!uvs.empty()) RT_HIP(hipMemcpy(ctx->dUVs, uvs.data(), uvs.size() * sizeof(PackedUV), hipMemcpyHostToDevice));
     if ((rc = devAlloc(ctx, &ctx->dModelDesc, descs.size())) != RT_OK) return rc;
     if (!nodes.empty()) RT_HIP(hipMemcpy(ctx->dNodes, nodes.data(), nodes.size() * sizeof(PackedNode), hipMemcpyHostToDevice));
     if (!tris.empty()) RT_HIP(hipMemcpy(ctx->dTris, tris.data(), tris.size() * sizeof(PackedTri), hipMemcpyHostToDevice));
@@ -1712,6 +1724,7 @@ static int commitScene(rt_ctx *ctx, int objectCount, int modelsCount, int lightS
     v.wtris = ctx->wideNow ? ctx->dWTris : nullptr;
     v.tris = ctx->dTris;
     v.shade = ctx->dShade;
+    v.uvs = ctx->dUVs;
     v.modelDesc = ctx->dModelDesc;
     v.objectCount = objectCount;
     v.modelsCount = modelsCount;

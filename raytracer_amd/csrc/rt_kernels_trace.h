@@ -58,7 +58,7 @@ __device__ __forceinline__ void orderPair(float &da, int32_t &ca, float &db, int
 // runs it in a phase of its own, where no node or triangle temporaries are live.
 __device__ __forceinline__ bool alphaCutRejects(const SceneView &sc, uint32_t tri, V3 ro, V3 rd, float t) {
     const PackedTri &pt = sc.tris[tri];
-    const PackedShade &ps = sc.shade[tri];
+    const PackedUV &ps = sc.uvs[tri];
     const float *m = sc.materials + pt.material * kMaterialWords;
     int baseColor = f2i(m[1]);
     float alphaCut = m[20];
