@@ -105,8 +105,17 @@ struct ModelDesc {
     int32_t vertBase;           // word offset of vertex 0
     int32_t triBase;            // index of identifier 0 in the packed triangle array
     int32_t wideRootRef;        // child reference of the model's root in the four-wide tree (when that mode is on)
-    int32_t pad[2];
+    int32_t lightTriBase;       // index of the model's first light triangle in SceneView::lightTris
+    int32_t pad;
 };
+// A light triangle as sampleLightPoint needs it (the three positions and the area), gathered at commit from the
+// model's light identifiers and vertices with the same single-precision operations the sampling would run.
+struct __attribute__((aligned(16))) LightTri {
+    float p0[3], p1[3], p2[3];
+    float area;                 // 0.5 * length(cross(p1 - p0, p2 - p0))
+    float pad[2];
+};
+static_assert(sizeof(LightTri) == 48, "light triangle record must be three 16-byte pieces");
 
 struct SceneView {
     const float *objects, *materials, *modelInfo, *models, *textures;
@@ -116,6 +125,7 @@ struct SceneView {
     const PackedTri *tris;
     const PackedShade *shade;   // [triangle], same index as tris
     const PackedUV *uvs;        // [triangle], same index as tris
+    const LightTri *lightTris;  // light triangles of all models, a model's at ModelDesc::lightTriBase
     const PackedTri *wtris;     // four-wide trees: the triangles in THEIR leaf order; `ident` holds the index into tris
     const TriPair *wpairs;      // four-wide trees of scenes without alpha-cut textures: the leaves as triangle pairs (leaf references then count pairs)
     const ModelDesc *modelDesc;
@@ -390,18 +400,16 @@ RT_FN V3 sampleLightPoint(const SceneView &sc, uint32_t &seed, float &area, floa
     int pick = (int)(rand_u32(seed) % (uint32_t)sc.lightSourcesCount);
     const ModelDesc &md = sc.modelDesc[pick];
     lightTriangleCount = (float)md.lightSourcesCount;
-    int identAt = md.lightBase + (int)(rand_u32(seed) % (uint32_t)md.lightSourcesCount) * kIdentWords;
-    int32_t idx[3] = {ldi(sc.models, identAt), ldi(sc.models, identAt + 1), ldi(sc.models, identAt + 2)};
-    TriVerts tv;
-    loadTriVerts(sc, md.vertBase, idx, tv);
+    const LightTri &lt = sc.lightTris[md.lightTriBase + (int)(rand_u32(seed) % (uint32_t)md.lightSourcesCount)];
+    const V3 p0 = v3(lt.p0[0], lt.p0[1], lt.p0[2]), p1 = v3(lt.p1[0], lt.p1[1], lt.p1[2]), p2 = v3(lt.p2[0], lt.p2[1], lt.p2[2]);
     float r1 = rand_float(seed);
     float r2 = rand_float(seed);
     if (r1 + r2 > 1.0f) {
         r1 = 1.0f - r1;
         r2 = 1.0f - r2;
     }
-    area = 0.5f * length(cross(tv.p[1] - tv.p[0], tv.p[2] - tv.p[0]));
-    return r1 * tv.p[0] + r2 * tv.p[1] + (1.0f - r1 - r2) * tv.p[2];
+    area = lt.area;
+    return r1 * p0 + r2 * p1 + (1.0f - r1 - r2) * p2;
 }
 
 }  // namespace rtd

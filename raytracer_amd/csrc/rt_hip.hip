@@ -92,6 +92,7 @@ struct rt_ctx {
     PackedTri *dTris = nullptr;
     PackedShade *dShade = nullptr;
     PackedUV *dUVs = nullptr;
+    LightTri *dLightTris = nullptr;
     ModelDesc *dModelDesc = nullptr;
     std::vector<PackedTri> hTris;   // kept for id decoding in rt_trace_primary
     SceneView view{};
@@ -289,7 +290,7 @@ int gridFor(const rt_ctx *ctx, uint64_t items, int blocksPerCU) {
 
 // Builds the traversal re-pack from the uploaded model streams and validates
 // every offset the kernels will follow.
-int repackScene(rt_ctx *ctx, std::vector<PackedNode> &nodes, std::vector<PackedTri> &tris, std::vector<PackedShade> &shade, std::vector<PackedUV> &uvs, std::vector<ModelDesc> &descs) {
+int repackScene(rt_ctx *ctx, std::vector<PackedNode> &nodes, std::vector<PackedTri> &tris, std::vector<PackedShade> &shade, std::vector<PackedUV> &uvs, std::vector<LightTri> &lightTris, std::vector<ModelDesc> &descs) {
     const std::vector<float> &info = ctx->host[RT_SLOT_MODEL_INFO];
     const std::vector<float> &mdl = ctx->host[RT_SLOT_MODELS];
     const std::vector<float> &mats = ctx->host[RT_SLOT_MATERIALS];
@@ -358,11 +359,19 @@ int repackScene(rt_ctx *ctx, std::vector<PackedNode> &nodes, std::vector<PackedT
             int mat = f2i(mdl[(size_t)wordAt + 3]);
             return mat >= 0 && mat < materialCount;
         };
-        for (int l = 0; l < d.lightSourcesCount; ++l)
+        d.lightTriBase = (int32_t)lightTris.size();
+        for (int l = 0; l < d.lightSourcesCount; ++l) {
+            LightTri lt{};
+            float *corner[3] = {lt.p0, lt.p1, lt.p2};
             for (int k = 0; k < 3; ++k) {
                 int vi = f2i(mdl[(size_t)d.lightBase + (size_t)l * kIdentWords + k]);
                 if (vi < 0 || vi >= vertexCapacity) return RT_ERR_SCENE;
+                for (int c = 0; c < 3; ++c) corner[k][c] = mdl[(size_t)d.vertBase + (size_t)vi * 8 + (size_t)c];
             }
+            const V3 p0 = v3(lt.p0[0], lt.p0[1], lt.p0[2]), p1 = v3(lt.p1[0], lt.p1[1], lt.p1[2]), p2 = v3(lt.p2[0], lt.p2[1], lt.p2[2]);
+            lt.area = 0.5f * length(cross(p1 - p0, p2 - p0));   // as sampleRandomPointFromLightSouces computes it, src/RayScene.cpp:900-935
+            lightTris.push_back(lt);
+        }
 
         // Triangles in identifier (leaf) order.
         for (int t = 0; t < d.identifiersCount; ++t) {
@@ -1590,7 +1599,7 @@ void rt_destroy(rt_ctx *ctx) {
         if (d.copied) hipEventDestroy(d.copied);
     }
     for (float *p : ctx->dStream) if (p) hipFree(p);
-    void *owned[] = {ctx->dNodes, ctx->dWNodes, ctx->dW8Nodes, ctx->dWPairs, ctx->pb.overflow, ctx->pb.retrace, ctx->dWTris, ctx->dTris, ctx->dShade, ctx->dUVs, ctx->dModelDesc, ctx->accumExternal ? nullptr : (void *)ctx->dAccum, ctx->dPartial,
+    void *owned[] = {ctx->dNodes, ctx->dWNodes, ctx->dW8Nodes, ctx->dWPairs, ctx->pb.overflow, ctx->pb.retrace, ctx->dWTris, ctx->dTris, ctx->dShade, ctx->dUVs, ctx->dLightTris, ctx->dModelDesc, ctx->accumExternal ? nullptr : (void *)ctx->dAccum, ctx->dPartial,
                      ctx->pb.rays, ctx->pb.hits, ctx->pb.stA, ctx->pb.stB, ctx->pb.neeA, ctx->pb.neeB, ctx->pb.neeC,
                      ctx->pb.qExt[0], ctx->pb.qExt[1], ctx->pb.qShadow, ctx->pb.stages, ctx->pb.counters};
     for (void *p : owned) if (p) hipFree(p);
@@ -1632,6 +1641,7 @@ static int commitScene(rt_ctx *ctx, int objectCount, int modelsCount, int lightS
     std::vector<PackedTri> tris;
     std::vector<PackedShade> shade;
     std::vector<PackedUV> uvs;
+    std::vector<LightTri> lightTris;
     std::vector<ModelDesc> descs;
     // RT_COMMIT_TIMING=1 prints where a commit spends its host time.
     const bool timing = std::getenv("RT_COMMIT_TIMING") != nullptr;
@@ -1642,7 +1652,7 @@ static int commitScene(rt_ctx *ctx, int objectCount, int modelsCount, int lightS
         since = now;
     };
     auto mark = clockNow();
-    int rc = repackScene(ctx, nodes, tris, shade, uvs, descs);
+    int rc = repackScene(ctx, nodes, tris, shade, uvs, lightTris, descs);
     if (rc != RT_OK) return rc;
     lap("validate + re-pack", mark);
 
@@ -1704,6 +1714,8 @@ static int commitScene(rt_ctx *ctx, int objectCount, int modelsCount, int lightS
     if (!shade.empty()) RT_HIP(hipMemcpy(ctx->dShade, shade.data(), shade.size() * sizeof(PackedShade), hipMemcpyHostToDevice));
     if ((rc = devAlloc(ctx, &ctx->dUVs, uvs.size())) != RT_OK) return rc;
     if (!uvs.empty()) RT_HIP(hipMemcpy(ctx->dUVs, uvs.data(), uvs.size() * sizeof(PackedUV), hipMemcpyHostToDevice));
+    if ((rc = devAlloc(ctx, &ctx->dLightTris, lightTris.size())) != RT_OK) return rc;
+    if (!lightTris.empty()) RT_HIP(hipMemcpy(ctx->dLightTris, lightTris.data(), lightTris.size() * sizeof(LightTri), hipMemcpyHostToDevice));
     if ((rc = devAlloc(ctx, &ctx->dModelDesc, descs.size())) != RT_OK) return rc;
     if (!nodes.empty()) RT_HIP(hipMemcpy(ctx->dNodes, nodes.data(), nodes.size() * sizeof(PackedNode), hipMemcpyHostToDevice));
     if (!tris.empty()) RT_HIP(hipMemcpy(ctx->dTris, tris.data(), tris.size() * sizeof(PackedTri), hipMemcpyHostToDevice));
@@ -1725,6 +1737,7 @@ static int commitScene(rt_ctx *ctx, int objectCount, int modelsCount, int lightS
     v.tris = ctx->dTris;
     v.shade = ctx->dShade;
     v.uvs = ctx->dUVs;
+    v.lightTris = ctx->dLightTris;
     v.modelDesc = ctx->dModelDesc;
     v.objectCount = objectCount;
     v.modelsCount = modelsCount;
