@@ -288,6 +288,7 @@ def main():
                 "traffic_note": traffic_note,
                 # `frac` prices the kernel's algorithmic bytes against HBM although the caches serve most of
                 # them (it can exceed 1).  The limit that binds is the one below with the largest fraction.
+                "frac_note": "algorithmic bytes per launch / launch time / HBM peak; the L2s and the Infinity Cache serve most of these bytes, so this can reach or pass 1 and is no distance to a limit: `binding` and `limits` are",
                 "binding": (lim["binding"] if lim else None),
                 "binding_frac": (lim["limits"][lim["binding"]].get("frac", lim["limits"][lim["binding"]].get("frac_high")) if lim else None),
                 "limits": ({k: {kk: vv for kk, vv in v.items() if kk != "what"} for k, v in lim["limits"].items()} if lim else None),
