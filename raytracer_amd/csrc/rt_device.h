@@ -126,6 +126,7 @@ struct SceneView {
     const PackedShade *shade;   // [triangle], same index as tris
     const PackedUV *uvs;        // [triangle], same index as tris
     const LightTri *lightTris;  // light triangles of all models, a model's at ModelDesc::lightTriBase
+    const int32_t *primAt;      // [objectCount]: word offset of each analytic primitive's record in `objects`
     const PackedTri *wtris;     // four-wide trees: the triangles in THEIR leaf order; `ident` holds the index into tris
     const TriPair *wpairs;      // four-wide trees of scenes without alpha-cut textures: the leaves as triangle pairs (leaf references then count pairs)
     const ModelDesc *modelDesc;
@@ -339,16 +340,10 @@ RT_FN HitInfoD resolveHit(const SceneView &sc, V3 ro, V3 rd, const HitRec &h) {
     info.isPrimitive = (h.id & kPrimBit) != 0u;
 
     if (info.isPrimitive) {
-        // Walk the variable-length primitive stream to record `index` (src/RayScene.cpp:855-891).
-        int want = (int)(h.id & kIndexMask);
-        int at = 0, type = 0, material = 0;
-        for (int i = 0;; ++i) {
-            type = ldi(sc.objects, at);
-            material = ldi(sc.objects, at + 1);
-            at += 2;
-            if (i == want) break;
-            at += (type == 0) ? 4 : (type == 1) ? 10 : (type == 2) ? 18 : 0;
-        }
+        // Record `index` of the variable-length primitive stream (src/RayScene.cpp:855-891), found at commit.
+        int at = sc.primAt[h.id & kIndexMask];
+        const int type = ldi(sc.objects, at), material = ldi(sc.objects, at + 1);
+        at += 2;
         if (type == 0) {            // hitSphere, src/RayScene.cpp:461-464
             V3 center = ld3(sc.objects, at);
             float radius = ldw(sc.objects, at + 3);

@@ -93,6 +93,8 @@ struct rt_ctx {
     PackedShade *dShade = nullptr;
     PackedUV *dUVs = nullptr;
     LightTri *dLightTris = nullptr;
+    int32_t *dPrimAt = nullptr;     // word offset of every analytic primitive's record in the objects stream
+    std::vector<int32_t> hPrimAt;
     ModelDesc *dModelDesc = nullptr;
     std::vector<PackedTri> hTris;   // kept for id decoding in rt_trace_primary
     SceneView view{};
@@ -310,13 +312,16 @@ int repackScene(rt_ctx *ctx, std::vector<PackedNode> &nodes, std::vector<PackedT
         }
     }
 
-    // Primitive stream: objectCount well-formed records.
+    // Primitive stream: objectCount well-formed records.  Where each starts is kept for the shading kernels, which
+    // would otherwise walk the variable-length records up to the one that was hit.
+    ctx->hPrimAt.clear();
     {
         size_t at = 0;
         for (int i = 0; i < ctx->objectCount; ++i) {
             if (at + 2 > obj.size()) return RT_ERR_SCENE;
             int type = f2i(obj[at]), material = f2i(obj[at + 1]);
             if (material < 0 || material >= materialCount) return RT_ERR_SCENE;
+            ctx->hPrimAt.push_back((int32_t)at);
             at += 2;
             at += (type == 0) ? 4 : (type == 1) ? 10 : (type == 2) ? 18 : 0;
             if (type < 0 || type > 2 || at > obj.size()) return RT_ERR_SCENE;
@@ -1599,7 +1604,7 @@ void rt_destroy(rt_ctx *ctx) {
         if (d.copied) hipEventDestroy(d.copied);
     }
     for (float *p : ctx->dStream) if (p) hipFree(p);
-    void *owned[] = {ctx->dNodes, ctx->dWNodes, ctx->dW8Nodes, ctx->dWPairs, ctx->pb.overflow, ctx->pb.retrace, ctx->dWTris, ctx->dTris, ctx->dShade, ctx->dUVs, ctx->dLightTris, ctx->dModelDesc, ctx->accumExternal ? nullptr : (void *)ctx->dAccum, ctx->dPartial,
+    void *owned[] = {ctx->dNodes, ctx->dWNodes, ctx->dW8Nodes, ctx->dWPairs, ctx->pb.overflow, ctx->pb.retrace, ctx->dWTris, ctx->dTris, ctx->dShade, ctx->dUVs, ctx->dLightTris, ctx->dPrimAt, ctx->dModelDesc, ctx->accumExternal ? nullptr : (void *)ctx->dAccum, ctx->dPartial,
                      ctx->pb.rays, ctx->pb.hits, ctx->pb.stA, ctx->pb.stB, ctx->pb.neeA, ctx->pb.neeB, ctx->pb.neeC,
                      ctx->pb.qExt[0], ctx->pb.qExt[1], ctx->pb.qShadow, ctx->pb.stages, ctx->pb.counters};
     for (void *p : owned) if (p) hipFree(p);
@@ -1716,6 +1721,8 @@ static int commitScene(rt_ctx *ctx, int objectCount, int modelsCount, int lightS
     if (!uvs.empty()) RT_HIP(hipMemcpy(ctx->dUVs, uvs.data(), uvs.size() * sizeof(PackedUV), hipMemcpyHostToDevice));
     if ((rc = devAlloc(ctx, &ctx->dLightTris, lightTris.size())) != RT_OK) return rc;
     if (!lightTris.empty()) RT_HIP(hipMemcpy(ctx->dLightTris, lightTris.data(), lightTris.size() * sizeof(LightTri), hipMemcpyHostToDevice));
+    if ((rc = devAlloc(ctx, &ctx->dPrimAt, ctx->hPrimAt.size())) != RT_OK) return rc;
+    if (!ctx->hPrimAt.empty()) RT_HIP(hipMemcpy(ctx->dPrimAt, ctx->hPrimAt.data(), ctx->hPrimAt.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     if ((rc = devAlloc(ctx, &ctx->dModelDesc, descs.size())) != RT_OK) return rc;
     if (!nodes.empty()) RT_HIP(hipMemcpy(ctx->dNodes, nodes.data(), nodes.size() * sizeof(PackedNode), hipMemcpyHostToDevice));
     if (!tris.empty()) RT_HIP(hipMemcpy(ctx->dTris, tris.data(), tris.size() * sizeof(PackedTri), hipMemcpyHostToDevice));
@@ -1738,6 +1745,7 @@ static int commitScene(rt_ctx *ctx, int objectCount, int modelsCount, int lightS
     v.shade = ctx->dShade;
     v.uvs = ctx->dUVs;
     v.lightTris = ctx->dLightTris;
+    v.primAt = ctx->dPrimAt;
     v.modelDesc = ctx->dModelDesc;
     v.objectCount = objectCount;
     v.modelsCount = modelsCount;
