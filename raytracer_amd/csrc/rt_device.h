@@ -255,19 +255,6 @@ struct HitInfoD {
     MaterialD mat;
 };
 
-struct TriVerts {
-    V3 p[3], n[3];
-    V2 uv[3];
-};
-RT_FN void loadTriVerts(const SceneView &sc, int vertBase, const int32_t idx[3], TriVerts &tv) {
-    for (int k = 0; k < 3; ++k) {
-        const float *v = sc.models + vertBase + idx[k] * 8;
-        tv.p[k] = v3(v[0], v[1], v[2]);
-        tv.n[k] = v3(v[3], v[4], v[5]);
-        tv.uv[k] = v2(v[6], v[7]);
-    }
-}
-
 // Shading normal of a triangle hit (hitTriangle, src/RayScene.cpp:582-595).
 RT_FN V3 triangleNormal(V3 n0, V3 n1, V3 n2, V3 geometric, float u, float v) {
     if (dot(n0, n0) > 0.0f) {
