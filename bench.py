@@ -268,7 +268,7 @@ def main():
             "config": {
                 "workload": f"{args.scene} ({'procedural dragon-class mesh, ' if 'knot' in args.scene else ''}{triangles} triangles in {scene.models_count} models), "
                             f"{args.width}x{args.height}, {args.spp} spp per {'image' if tile_split else 'GPU'} per step, primary+{args.bounces} bounces, "
-                            f"{'Spectral' if args.spectral else 'RGB'} NEE+MIS" + (", hero-wavelength mode (4 wavelengths per camera sample)" if args.hero else "") + (", opt-in SAH trees (not the reference's traversal order)" if args.bvh == "sah" else "")
+                            f"{'Spectral' if args.spectral else 'RGB'} NEE+MIS" + (", hero-wavelength mode (4 wavelengths per camera sample; the camera ray they share is traced once and counted once)" if args.hero else "") + (", opt-in SAH trees (not the reference's traversal order)" if args.bvh == "sah" else "")
                             + (", " + TREES[wide]),
                 "sharding": (("tile-split 8x8 tiles" if tile_split else "sample-split frames") + f", scene replicated, {'RCCL' if args.dist_backend == 'nccl' else args.dist_backend} sum-reduce of the fp32 accumulation buffer") if distributed else "single GPU",
                 "rays_per_camera_sample": round(total_rays / max(total_samples, 1), 4),

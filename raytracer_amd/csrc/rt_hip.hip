@@ -1260,6 +1260,10 @@ int allocPathBuffers(rt_ctx *ctx, uint64_t want64) {
     const uint32_t want = (uint32_t)want64;
     ctx->P = 0;
     int rc;
+    if (ctx->pb.cameraHits != nullptr) {   // sized with the set; ensurePathBuffers makes it again when it is wanted
+        RT_HIP(hipFree(ctx->pb.cameraHits));
+        ctx->pb.cameraHits = nullptr;
+    }
     if ((rc = devAlloc(ctx, &ctx->pb.rays, (size_t)want * 2)) != RT_OK) return rc;
     if ((rc = devAlloc(ctx, &ctx->pb.hits, (size_t)want * 2)) != RT_OK) return rc;
     if ((rc = devAlloc(ctx, &ctx->pb.stA, want)) != RT_OK) return rc;
@@ -1302,13 +1306,22 @@ int ensurePathBuffers(rt_ctx *ctx, uint64_t wantedPaths) {
         ceiling = std::min<uint64_t>(ceiling, (freeBytes / 2 + (uint64_t)ctx->P * perPath) / perPath);
     }
     uint64_t planes = std::max<uint64_t>(1, std::min<uint64_t>(ceiling / npt, (wantedPaths + npt - 1) / npt));
-    if (ctx->pb.rays != nullptr && ctx->P >= planes * npt) return RT_OK;
-    // If the device cannot give that much after all, retry with half the planes.
-    for (;; planes = (planes + 1) / 2) {
-        const int rc = allocPathBuffers(ctx, planes * npt);
-        if (rc == RT_OK || rc != RT_ERR_HIP || planes == 1) return rc;
+    if (!(ctx->pb.rays != nullptr && ctx->P >= planes * npt)) {
+        // If the device cannot give that much after all, retry with half the planes.
+        for (;; planes = (planes + 1) / 2) {
+            const int rc = allocPathBuffers(ctx, planes * npt);
+            if (rc == RT_OK) break;
+            if (rc != RT_ERR_HIP || planes == 1) return rc;
+            (void)hipGetLastError();
+        }
+    }
+    // Hero-wavelength mode keeps the camera rays' hit records of a sample's first wavelength for the other three.
+    // Without room for them every wavelength traces its own camera rays.
+    if (ctx->fp.hero && ctx->pb.cameraHits == nullptr && devAlloc(ctx, &ctx->pb.cameraHits, ctx->P) != RT_OK) {
+        ctx->pb.cameraHits = nullptr;
         (void)hipGetLastError();
     }
+    return RT_OK;
 }
 
 void launchTrace(rt_ctx *ctx, int extParity, int stage, uint64_t maxRays) {
@@ -1385,13 +1398,22 @@ int runBatch(rt_ctx *ctx, const Batch &bt) {
     const int gGen = gridFor(ctx, paths, 16), gShade = gridFor(ctx, paths, 8);
     // Hero-wavelength mode runs the whole bounce loop once per wavelength of the camera sample.
     const int passes = (spectral && fp.hero) ? 4 : 1;
+
     for (int pass = 0; pass < passes; ++pass) {
         RT_HIP(hipMemsetAsync(ctx->pb.stages, 0, sizeof(Stage) * ((size_t)fp.bounces + 2), ctx->stream));
         if (spectral) hipLaunchKernelGGL(k_generate<true>, dim3(gGen), dim3(kBlock), 0, ctx->stream, fp, bt, ctx->pb, fp.hero ? pass : -1);
         else hipLaunchKernelGGL(k_generate<false>, dim3(gGen), dim3(kBlock), 0, ctx->stream, fp, bt, ctx->pb, -1);
 
         for (int b = 0; b <= fp.bounces; ++b) {
-            launchTrace(ctx, b & 1, b, b == 0 ? paths : 2 * paths);
+            // The four wavelengths of a camera sample start along the same camera ray (same seed, src/RayTracer.cpp:1051,
+            // 1357-1364): the camera rays are traced for the first and their hit records kept for the other three.
+            const bool sameCameraRays = passes > 1 && b == 0 && ctx->pb.cameraHits != nullptr;
+            if (sameCameraRays && pass > 0) {
+                RT_HIP(hipMemcpyAsync(ctx->pb.hits, ctx->pb.cameraHits, (size_t)paths * sizeof(HitRec), hipMemcpyDeviceToDevice, ctx->stream));
+            } else {
+                launchTrace(ctx, b & 1, b, b == 0 ? paths : 2 * paths);
+                if (sameCameraRays) RT_HIP(hipMemcpyAsync(ctx->pb.cameraHits, ctx->pb.hits, (size_t)paths * sizeof(HitRec), hipMemcpyDeviceToDevice, ctx->stream));
+            }
             if (b > 0 && fp.nee) {   // without NEE there are no shadow rays to connect
                 if (spectral) hipLaunchKernelGGL(k_connect<true>, dim3(gShade), dim3(kBlock), 0, ctx->stream, ctx->view, bt, ctx->pb, b, cnt, fp.shadowEarlyOut);
                 else hipLaunchKernelGGL(k_connect<false>, dim3(gShade), dim3(kBlock), 0, ctx->stream, ctx->view, bt, ctx->pb, b, cnt, fp.shadowEarlyOut);
@@ -1592,7 +1614,7 @@ void rt_destroy(rt_ctx *ctx) {
     syncAllStreams(ctx);
     for (rt_ctx::Pipe &pipe : ctx->pipes) {
         void *mine[] = {pipe.pb.rays, pipe.pb.hits, pipe.pb.stA, pipe.pb.stB, pipe.pb.neeA, pipe.pb.neeB, pipe.pb.neeC, pipe.pb.qExt[0], pipe.pb.qExt[1],
-                        pipe.pb.qShadow, pipe.pb.stages, pipe.pb.retrace, pipe.pb.overflow};   // the counters belong to pipe 0
+                        pipe.pb.qShadow, pipe.pb.stages, pipe.pb.retrace, pipe.pb.overflow, pipe.pb.cameraHits};   // the counters belong to pipe 0
         for (void *p : mine) if (p) hipFree(p);
         if (pipe.stream) hipStreamDestroy(pipe.stream);
         if (pipe.fence) hipEventDestroy(pipe.fence);
@@ -1606,7 +1628,7 @@ void rt_destroy(rt_ctx *ctx) {
     for (float *p : ctx->dStream) if (p) hipFree(p);
     void *owned[] = {ctx->dNodes, ctx->dWNodes, ctx->dW8Nodes, ctx->dWPairs, ctx->pb.overflow, ctx->pb.retrace, ctx->dWTris, ctx->dTris, ctx->dShade, ctx->dUVs, ctx->dLightTris, ctx->dPrimAt, ctx->dModelDesc, ctx->accumExternal ? nullptr : (void *)ctx->dAccum, ctx->dPartial,
                      ctx->pb.rays, ctx->pb.hits, ctx->pb.stA, ctx->pb.stB, ctx->pb.neeA, ctx->pb.neeB, ctx->pb.neeC,
-                     ctx->pb.qExt[0], ctx->pb.qExt[1], ctx->pb.qShadow, ctx->pb.stages, ctx->pb.counters};
+                     ctx->pb.qExt[0], ctx->pb.qExt[1], ctx->pb.qShadow, ctx->pb.stages, ctx->pb.counters, ctx->pb.cameraHits};
     for (void *p : owned) if (p) hipFree(p);
     drainEvents(ctx);
     closeComm(ctx);

@@ -119,6 +119,9 @@ struct PathBuffers {
     // stage's retrace.count (it may exceed the capacity: the surplus is not stored).
     uint32_t *retrace;
     uint32_t retraceCap;
+    // Hero-wavelength mode: the camera rays' hit records of the sample's first wavelength, kept for the other
+    // three, which start along the same camera rays ([P], allocated when the mode is first used).
+    HitRec *cameraHits;
 };
 
 __device__ __forceinline__ uint32_t laneId() { return threadIdx.x & 63u; }
