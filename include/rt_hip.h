@@ -271,8 +271,12 @@ int rt_set_counters(rt_ctx *ctx, int enabled);
  *                            (src/RayTracer.cpp:607, 1257-1280, 1357-1364): every camera sample traces
  *                            four wavelengths, spread over the range from one random offset, along
  *                            the same camera ray and each from the same seed (it is passed by value,
- *                            src/RayTracer.cpp:1051), and adds the mean of their XYZ contributions.  Four times the rays per
- *                            sample.  Default 0, the reference's default.  Ignored by RT_TYPE_RGB.
+ *                            src/RayTracer.cpp:1051), and adds the mean of their XYZ contributions.  Four
+ *                            times the bounce loop per sample; the camera ray the four share is traced
+ *                            once and its hit record kept for the other three (16 bytes of device
+ *                            memory per path; rt_stats.rays counts the rays traced, three per camera
+ *                            sample fewer than the shader's).  Default 0, the reference's default.
+ *                            Ignored by RT_TYPE_RGB.
  *   RT_OPT_NEE               0: both integrators as built with ENABLE_NEE 0 (src/RayTracer.cpp:24,
  *                            606): no light sampling and no shadow rays, every emitter hit counts
  *                            in full (:357-376, :420-481, :1077-1091, :1147-1203).  Default 1.
