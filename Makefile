@@ -22,9 +22,20 @@ HOST_HDRS := $(wildcard $(HOST)/*.h $(HOST)/gpu/*.h $(HOST)/glm/*.hpp $(HOST)/gl
 
 all: $(LIBDIR)/librt_hip.so $(LIBDIR)/librt_host.so oracle/liboracle.so examples/rt_render
 
-$(LIBDIR)/librt_hip.so: $(CSRC)/rt_hip.hip $(wildcard $(CSRC)/*.h) include/rt_hip.h
-	@mkdir -p $(LIBDIR)
-	$(HIPCC) $(HIPFLAGS) -shared $(CSRC)/rt_hip.hip -o $@
+# The device assembly is kept (build/*.s) and audited before the library is installed: hand-written
+# instructions next to a transcendental result they read (a hazard the compiler does not see inside asm
+# blocks), and spill bytes of every kernel against the audited figures of tools/spill_budget.json.
+BUILD := build
+DEVICE_ASM := $(BUILD)/rt_hip-hip-amdgcn-amd-amdhsa-$(ARCH).s
+$(LIBDIR)/librt_hip.so: $(CSRC)/rt_hip.hip $(wildcard $(CSRC)/*.h) include/rt_hip.h tools/isa_audit.py tools/spill_budget.json
+	@mkdir -p $(LIBDIR) $(BUILD)
+	cd $(BUILD) && $(HIPCC) $(subst -Iinclude,-I$(CURDIR)/include,$(subst -I$(CSRC),-I$(CURDIR)/$(CSRC),$(HIPFLAGS))) $(EXTRA_HIPFLAGS) -save-temps -shared $(CURDIR)/$(CSRC)/rt_hip.hip -o librt_hip.so
+	python3 tools/isa_audit.py $(DEVICE_ASM) --budget tools/spill_budget.json
+	cp $(BUILD)/librt_hip.so $@
+
+# Re-records the spill figures after a change that was looked at (tools/isa_audit.py --list shows them).
+spill-budget:
+	python3 tools/isa_audit.py $(DEVICE_ASM) --budget tools/spill_budget.json --write-budget
 
 $(LIBDIR)/librt_host.so: $(HOST_SRCS) $(HOST_HDRS) $(LIBDIR)/librt_hip.so
 	@mkdir -p $(LIBDIR)
@@ -38,6 +49,7 @@ oracle/liboracle.so: oracle/oracle.cpp oracle/oracle_spectral.inc $(CSRC)/rt_mat
 	$(MAKE) -C oracle liboracle.so
 
 clean:
+	rm -rf $(BUILD)
 	rm -f $(LIBDIR)/*.so oracle/liboracle.so examples/rt_render
 
-.PHONY: all clean
+.PHONY: all clean spill-budget

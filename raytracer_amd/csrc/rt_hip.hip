@@ -1369,7 +1369,7 @@ void launchTrace(rt_ctx *ctx, int extParity, int stage, uint64_t maxRays) {
     // then refills its lanes a few times instead of every wave walking one under-filled batch to its
     // slowest ray's end, which is vector work for idle lanes (+14 % frames/s at 960x540; batches of
     // more than ~2.8 M rays are not affected).
-    if (ctx->countersOn) wavesPerSimd = std::min(wavesPerSimd, kCountingWaves);
+    if (ctx->countersOn && kCountingWaves > 0) wavesPerSimd = std::min(wavesPerSimd, kCountingWaves);
     const int fullGrid = ctx->numCUs * wavesPerSimd;
     constexpr int handsPerWave = 6;   // 64-ray hands a wave should get to deal with (swept 2..12: 3 -> -4 %, 12 -> -8 %)
     const uint64_t fewRaysGrid = std::max<uint64_t>(maxRays / (64 * handsPerWave * (kBlock / 64)), (uint64_t)ctx->numCUs);

@@ -8,10 +8,13 @@ using namespace rtd;
 
 namespace {
 
-// Waves per SIMD the counting instances are compiled for: their nine extra counters do not fit the
-// register budget of the plain instances (at 6-7 waves/SIMD the four-wide alpha-cut counting instance
-// spilled 64-68 bytes per lane and returned wrong images), and nobody times them.
-constexpr int kCountingWaves = 4;
+// Waves per SIMD the counting instances are compiled for: nobody times them, and at the plain instances'
+// budget their nine extra counters cost 14-24 spilled registers.  -DRT_WCOUNT=0 gives them the plain
+// instances' bounds (they are correct there too; tools/r03_hazard_experiment.sh).
+#ifndef RT_WCOUNT
+#define RT_WCOUNT 4
+#endif
+constexpr int kCountingWaves = RT_WCOUNT;
 
 // ---- k_trace ----------------------------------------------------------------------------
 // RayBoundingBoxDst, src/RayScene.cpp:417-431, with 1/direction hoisted per ray.
@@ -231,7 +234,7 @@ __device__ __forceinline__ void intersectPrimitives(const SceneView &sc, LaneRay
 // ray but slower, because lanes then mix the small models' leaves with the large model's inner
 // nodes and the two phases of the loop run emptier.)
 template <bool COUNT, int STACK, bool ALPHA, bool PRIMS, bool ROOTS, bool WIDE, bool RETRACE = false>
-__global__ __launch_bounds__(kBlock, COUNT ? kCountingWaves : WIDE ? ((ALPHA && PRIMS) ? RT_WWIDE_ALPHA : RT_WWIDE)
+__global__ __launch_bounds__(kBlock, (COUNT && kCountingWaves > 0) ? kCountingWaves : WIDE ? ((ALPHA && PRIMS) ? RT_WWIDE_ALPHA : RT_WWIDE)
                                           : (STACK <= 20 ? (ALPHA ? RT_WALPHA : PRIMS ? 7 : RT_W20) : STACK <= 24 ? (ALPHA ? (RT_WALPHA < 6 ? RT_WALPHA : 6) : 6) : 5)) void k_trace(SceneView sc, PathBuffers pb, int extParity, int stage, int refillLanes, int innerShare) {
     // Four-wide instances write a hit record the moment a hit is accepted (the primitives' best hit when the ray
     // starts, then every accepted triangle) and keep only "this model has a hit" (bit 31 of the model number),
@@ -472,7 +475,7 @@ __global__ __launch_bounds__(kBlock, COUNT ? kCountingWaves : WIDE ? ((ALPHA && 
                         // reciprocal will do.  Plane numbers are scaled by inv, so keep it finite (a
                         // direction component of zero then behaves like a very small one of the same sign).
                         r.inv = v3(__builtin_amdgcn_rcpf(r.rd.x), __builtin_amdgcn_rcpf(r.rd.y), __builtin_amdgcn_rcpf(r.rd.z));
-                        r.inv = v3(fminI_(fmaxI_(r.inv.x, -1e18f), 1e18f), fminI_(fmaxI_(r.inv.y, -1e18f), 1e18f), fminI_(fmaxI_(r.inv.z, -1e18f), 1e18f));
+                        r.inv = v3(clampMag_(r.inv.x, 1e18f), clampMag_(r.inv.y, 1e18f), clampMag_(r.inv.z, 1e18f));   // (not fminI_/fmaxI_: the operand is a v_rcp_f32 result)
                     } else {
                         r.inv = v3(1.0f / r.rd.x, 1.0f / r.rd.y, 1.0f / r.rd.z);
                     }

@@ -62,7 +62,7 @@ struct LaneRay8 {
 };
 
 template <bool COUNT, bool PRIMS, bool ROOTS>
-__global__ __launch_bounds__(kBlock, COUNT ? kCountingWaves : RT_W8) void k_trace8(SceneView sc, PathBuffers pb, int extParity, int stage, int refillLanes, int innerShare) {
+__global__ __launch_bounds__(kBlock, (COUNT && kCountingWaves > 0) ? kCountingWaves : RT_W8) void k_trace8(SceneView sc, PathBuffers pb, int extParity, int stage, int refillLanes, int innerShare) {
     __shared__ uint2v stackLds[kBlock / 64][kWide8Stack][64];
     __shared__ int32_t rootTable[ROOTS ? kRootCache : 1];
     const uint32_t lane = laneId();
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(kBlock, COUNT ? kCountingWaves : RT_W8) void k_trac
                     r.rd = v3(r1.x, r1.y, r1.z);
                     // Box tests only (the boxes carry a margin): the one-instruction reciprocal, kept finite.
                     r.inv = v3(__builtin_amdgcn_rcpf(r.rd.x), __builtin_amdgcn_rcpf(r.rd.y), __builtin_amdgcn_rcpf(r.rd.z));
-                    r.inv = v3(fminI_(fmaxI_(r.inv.x, -1e18f), 1e18f), fminI_(fmaxI_(r.inv.y, -1e18f), 1e18f), fminI_(fmaxI_(r.inv.z, -1e18f), 1e18f));
+                    r.inv = v3(clampMag_(r.inv.x, 1e18f), clampMag_(r.inv.y, 1e18f), clampMag_(r.inv.z, 1e18f));   // (not fminI_/fmaxI_: the operand is a v_rcp_f32 result)
                     r.oct4 = ((r.inv.x < 0.0f ? 1u : 0u) | (r.inv.y < 0.0f ? 2u : 0u) | (r.inv.z < 0.0f ? 4u : 0u)) * 0x01010101u;
                     r.tStop = r1.w > 0.0f ? r1.w : 0.0f;
                     if (PRIMS) {

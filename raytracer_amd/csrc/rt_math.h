@@ -59,10 +59,18 @@ RT_FN float fmax_(float a, float b) { return __builtin_fmaxf(a, b); }
 // v_min_f32 / v_max_f32 are minNum / maxNum for quiet NaNs, and arithmetic never produces a
 // signalling one; the compiler cannot know that and puts a canonicalising v_max_f32 x, x in
 // front of operands of the builtins (14 extra instructions per opened tree node).
+// Hand-written instructions are invisible to the compiler's hazard recogniser: on gfx950 a vector
+// instruction that reads the result of a transcendental one (v_rcp_f32, v_rsq_f32, v_sqrt_f32 ...)
+// needs one instruction in between, and the hardware does not wait by itself.  Operands of these four
+// must therefore never come straight from such an instruction; clampMag_ below is for that case
+// (tools/isa_audit.py checks the generated code for the pair).
 RT_FN float fminI_(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 RT_FN float fmaxI_(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 RT_FN float fmin3_(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 RT_FN float fmax3_(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+// min(max(x, -m), m) as one instruction the compiler knows (v_med3_f32), so that it can keep the
+// required distance from a transcendental instruction that produced x.
+RT_FN float clampMag_(float x, float m) { return __builtin_amdgcn_fmed3f(x, -m, m); }
 #else
 RT_FN float fmin_(float a, float b) { return (a != a) ? b : ((b < a) ? b : a); }
 RT_FN float fmax_(float a, float b) { return (a != a) ? b : ((b > a) ? b : a); }
@@ -70,6 +78,7 @@ RT_FN float fminI_(float a, float b) { return fmin_(a, b); }
 RT_FN float fmaxI_(float a, float b) { return fmax_(a, b); }
 RT_FN float fmin3_(float a, float b, float c) { return fmin_(fmin_(a, b), c); }
 RT_FN float fmax3_(float a, float b, float c) { return fmax_(fmax_(a, b), c); }
+RT_FN float clampMag_(float x, float m) { return fmin_(fmax_(x, -m), m); }
 #endif
 RT_FN float clamp_(float x, float lo, float hi) { return fmin_(fmax_(x, lo), hi); }
 RT_FN float abs_(float x) { return u2f(f2u(x) & 0x7fffffffu); }
