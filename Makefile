@@ -27,11 +27,46 @@ all: $(LIBDIR)/librt_hip.so $(LIBDIR)/librt_host.so oracle/liboracle.so examples
 # blocks), and spill bytes of every kernel against the audited figures of tools/spill_budget.json.
 BUILD := build
 DEVICE_ASM := $(BUILD)/rt_hip-hip-amdgcn-amd-amdhsa-$(ARCH).s
-$(LIBDIR)/librt_hip.so: $(CSRC)/rt_hip.hip $(wildcard $(CSRC)/*.h) include/rt_hip.h tools/isa_audit.py tools/spill_budget.json
+# Host-only parts of the backend (stream validation, re-pack, tree builds; RCCL binding) are plain C++ built by
+# g++: the sanitizer targets below build the same files without a GPU toolchain.
+COMMIT_FLAGS := -std=c++17 -O2 -fPIC -ffp-contract=off -fno-fast-math -pthread -Wall -Wextra -Iinclude -I$(CSRC)
+$(BUILD)/rt_commit.o: $(CSRC)/rt_commit.cpp $(CSRC)/rt_commit.h $(CSRC)/rt_device.h $(CSRC)/rt_math.h include/rt_hip.h
+	@mkdir -p $(BUILD)
+	$(CXX) $(COMMIT_FLAGS) -c $< -o $@
+$(BUILD)/rt_comm.o: $(CSRC)/rt_comm.cpp $(CSRC)/rt_comm.h include/rt_hip.h
+	@mkdir -p $(BUILD)
+	$(CXX) $(COMMIT_FLAGS) -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -c $< -o $@
+
+$(LIBDIR)/librt_hip.so: $(CSRC)/rt_hip.hip $(wildcard $(CSRC)/*.h) include/rt_hip.h $(BUILD)/rt_commit.o $(BUILD)/rt_comm.o tools/isa_audit.py tools/spill_budget.json
 	@mkdir -p $(LIBDIR) $(BUILD)
-	cd $(BUILD) && $(HIPCC) $(subst -Iinclude,-I$(CURDIR)/include,$(subst -I$(CSRC),-I$(CURDIR)/$(CSRC),$(HIPFLAGS))) $(EXTRA_HIPFLAGS) -save-temps -shared $(CURDIR)/$(CSRC)/rt_hip.hip -o librt_hip.so
+	cd $(BUILD) && $(HIPCC) $(subst -Iinclude,-I$(CURDIR)/include,$(subst -I$(CSRC),-I$(CURDIR)/$(CSRC),$(HIPFLAGS))) $(EXTRA_HIPFLAGS) -save-temps -c $(CURDIR)/$(CSRC)/rt_hip.hip -o rt_hip.o
+	$(HIPCC) --offload-arch=$(ARCH) -fPIC -pthread -shared $(BUILD)/rt_hip.o $(BUILD)/rt_commit.o $(BUILD)/rt_comm.o -o $(BUILD)/librt_hip.so
 	python3 tools/isa_audit.py $(DEVICE_ASM) --budget tools/spill_budget.json
 	cp $(BUILD)/librt_hip.so $@
+
+# Sanitizer builds of everything that runs on the CPU (g++ only, no GPU toolchain): the host layer, the image and
+# glTF readers and the commit-time code of the backend, driven by tools/fuzz_host.cpp (which stands in for the
+# backend's entry points).  `make asan` / `make tsan` build build/fuzz_host_asan / build/fuzz_host_tsan;
+# `make sanitize` runs the self-test and a bounded fuzz pass under both.
+FUZZ_SRCS := tools/fuzz_host.cpp $(CSRC)/rt_commit.cpp $(filter-out $(HOST)/gpu/HipStorage.cpp,$(HOST_SRCS)) $(HOST)/gpu/HipStorage.cpp
+SAN_FLAGS := -std=c++17 -O1 -g -fno-omit-frame-pointer -ffp-contract=off -pthread -Iinclude -I$(CSRC) -I$(HOST)
+asan: $(BUILD)/fuzz_host_asan
+tsan: $(BUILD)/fuzz_host_tsan
+$(BUILD)/fuzz_host_asan: $(FUZZ_SRCS) $(HOST_HDRS) $(CSRC)/rt_commit.h
+	@mkdir -p $(BUILD)
+	$(CXX) $(SAN_FLAGS) -fsanitize=address,undefined -fno-sanitize-recover=undefined $(FUZZ_SRCS) -o $@ -lz
+$(BUILD)/fuzz_host_tsan: $(FUZZ_SRCS) $(HOST_HDRS) $(CSRC)/rt_commit.h
+	@mkdir -p $(BUILD)
+	$(CXX) $(SAN_FLAGS) -fsanitize=thread $(FUZZ_SRCS) -o $@ -lz
+FUZZ_N ?= 20000
+sanitize: asan tsan
+	python3 tools/make_fuzz_seeds.py $(BUILD)/fuzz_seeds
+	$(BUILD)/fuzz_host_asan selftest
+	$(BUILD)/fuzz_host_asan streams $(FUZZ_N) 1
+	$(BUILD)/fuzz_host_asan png $(FUZZ_N) 2 $(BUILD)/fuzz_seeds/*.png
+	$(BUILD)/fuzz_host_asan jpeg $(FUZZ_N) 3 $(BUILD)/fuzz_seeds/*.jpg
+	$(BUILD)/fuzz_host_asan glb 2000 4 $(BUILD)/fuzz_seeds/*.glb tests/golden/room.glb
+	$(BUILD)/fuzz_host_tsan selftest
 
 # Re-records the spill figures after a change that was looked at (tools/isa_audit.py --list shows them).
 spill-budget:
@@ -52,4 +87,4 @@ clean:
 	rm -rf $(BUILD)
 	rm -f $(LIBDIR)/*.so oracle/liboracle.so examples/rt_render
 
-.PHONY: all clean spill-budget
+.PHONY: all clean spill-budget asan tsan sanitize

@@ -1,0 +1,39 @@
+// rt_commit.h — interface between the HIP translation unit (rt_hip.hip: context, uploads, launches)
+// and the commit-time host work in rt_commit.cpp (plain C++: stream validation, re-pack, tree builds).
+#pragma once
+
+#include <cstdint>
+#include <vector>
+
+#include "rt_hip.h"      // status codes, slot numbers
+#include "rt_device.h"   // record layouts shared with the kernels
+
+// The part of a context the commit-time code reads and writes; rt_ctx derives from it.
+struct rt_scene_host {
+    std::vector<float> host[6];     // uploaded words per slot (1..5)
+    int objectCount = 0, modelsCount = 0, lightSourcesCount = 0;
+    int wideBvh = 3;                // asked for: 0 off, 1 derived from the uploaded trees, 2 the library's own trees, 3 = 2 + ties re-traced in reference order, 4 = 3 on eight-wide trees
+    // results of repackScene
+    std::vector<int32_t> hPrimAt;   // word offset of every analytic primitive's record in the objects stream
+    int maxTreeDepth = 0;           // deepest uploaded tree
+    bool hasAlphaTest = false;      // some triangle needs the alpha-cut texture test
+    // result of buildWideNodes / buildWide8
+    int wideStackNeed = 0;          // most stack entries a ray can hold in the wide tree
+};
+
+namespace rtc {
+
+// Builds the traversal re-pack from the uploaded model streams and validates every offset the
+// kernels will follow.  RT_ERR_SCENE for a stream the kernels could not walk safely.
+int repackScene(rt_scene_host *ctx, std::vector<rtd::PackedNode> &nodes, std::vector<rtd::PackedTri> &tris, std::vector<rtd::PackedShade> &shade,
+                std::vector<rtd::PackedUV> &uvs, std::vector<rtd::LightTri> &lightTris, std::vector<rtd::ModelDesc> &descs);
+// Four-wide trees of every model (ctx->wideBvh 1: collapsed from the uploaded trees; >= 2: from the library's own).
+int buildWideNodes(rt_scene_host *ctx, std::vector<rtd::ModelDesc> &descs, std::vector<rtd::WideNode> &wnodes, const std::vector<rtd::PackedTri> &tris,
+                   std::vector<rtd::PackedTri> &wtris);
+// Re-packs the leaves of four-wide trees as triangle pairs; leaf references then count pairs.
+void pairLeaves(std::vector<rtd::WideNode> &wnodes, std::vector<rtd::ModelDesc> &descs, const std::vector<rtd::PackedTri> &wtris, std::vector<rtd::TriPair> &wpairs);
+// Eight-wide trees over the library's own binary trees.
+int buildWide8(rt_scene_host *ctx, std::vector<rtd::ModelDesc> &descs, std::vector<rtd::Wide8Node> &w8, const std::vector<rtd::PackedTri> &tris,
+               std::vector<rtd::PackedTri> &w8tris);
+
+}  // namespace rtc

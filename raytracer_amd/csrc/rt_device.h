@@ -164,6 +164,7 @@ constexpr float kMinDenominator = 1e-8f;   // MIN_DENOMINATOR, src/RayTracer.cpp
 constexpr float kPi = 3.1415926f;          // src/RayTracer.cpp:31-33
 constexpr float kInvPi = 1.0f / kPi;
 constexpr float kRad = kPi / 180.0f;
+constexpr int kStackDepth = 32;            // int stack[32], src/RayScene.cpp:682: deepest tree the walk can hold
 constexpr int kIdentWords = 5;             // src/RayScene.cpp:674-675
 constexpr int kNodeWords = 9;
 constexpr int kMaterialWords = 23;         // 92 / 4, src/RayScene.cpp:387

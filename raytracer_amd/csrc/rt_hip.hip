@@ -28,8 +28,6 @@
 // Build with -ffp-contract=off (see rt_math.h).
 
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
-#include <dlfcn.h>
 
 #include <algorithm>
 #include <array>
@@ -46,8 +44,11 @@
 
 #include "rt_hip.h"
 #include "rt_bsdf.h"
+#include "rt_commit.h"
+#include "rt_comm.h"
 
 using namespace rtd;
+using namespace rtc;
 
 #include "rt_wavefront.h"
 #include "rt_kernels_frame.h"
@@ -66,35 +67,30 @@ using namespace rtd;
 constexpr size_t kDisplayScratchBytes = 32u << 20;   // 8 Mi pixels: frames up to 3840x2160
 static __device__ __align__(256) unsigned char scratch[kDisplayScratchBytes];
 
-struct rt_ctx {
+struct rt_ctx : rt_scene_host {
     int device = 0;
     hipStream_t stream = nullptr;
     std::string hipError;
     uchar4 *displayScratch = nullptr;   // this device's copy of `scratch` (hipGetSymbolAddress)
 
-    std::vector<float> host[6];     // uploaded words per slot (1..5)
     float *dStream[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t dStreamWords[6] = {0, 0, 0, 0, 0, 0};
     bool dirty = true;
 
-    int objectCount = 0, modelsCount = 0, lightSourcesCount = 0;
     bool committed = false;
     PackedNode *dNodes = nullptr;
     WideNode *dWNodes = nullptr;    // four-wide tree (wideBvh only)
     Wide8Node *dW8Nodes = nullptr;  // eight-wide tree (wideBvh 4)
     TriPair *dWPairs = nullptr;     // leaves of the four-wide trees as triangle pairs (scenes without alpha-cut textures)
-    int wideBvh = 3;                // asked for: 0 off, 1 derived from the uploaded trees, 2 the library's own trees, 3 = 2 + ties re-traced in reference order, 4 = 3 on eight-wide trees
     bool wideChosen = false;        // by option or environment: then a scene the four-wide build declines is an error
     int wideNow = 0;                // in effect for the committed scene (0 when the default was declined for it)
     PackedTri *dWTris = nullptr;    // triangles in wide-tree leaf order
-    int wideStackNeed = 0;          // most stack entries a ray can hold in the wide tree
     uint32_t overflowWords = 0;     // 4-byte words per lane allocated in pb.overflow
     PackedTri *dTris = nullptr;
     PackedShade *dShade = nullptr;
     PackedUV *dUVs = nullptr;
     LightTri *dLightTris = nullptr;
     int32_t *dPrimAt = nullptr;     // word offset of every analytic primitive's record in the objects stream
-    std::vector<int32_t> hPrimAt;
     ModelDesc *dModelDesc = nullptr;
     std::vector<PackedTri> hTris;   // kept for id decoding in rt_trace_primary
     SceneView view{};
@@ -114,8 +110,6 @@ struct rt_ctx {
     PathBuffers pb{};
     bool countersOn = false;
     int numCUs = 256;
-    int maxTreeDepth = 0;
-    bool hasAlphaTest = false;
     bool shadowEarlyOut = true;
     bool spectralPdfAsWritten = false;
     bool heroWavelength = false;
@@ -290,968 +284,7 @@ int gridFor(const rt_ctx *ctx, uint64_t items, int blocksPerCU) {
     return (int)((want + kSubQueues - 1) / kSubQueues * kSubQueues);
 }
 
-// Builds the traversal re-pack from the uploaded model streams and validates
-// every offset the kernels will follow.
-int repackScene(rt_ctx *ctx, std::vector<PackedNode> &nodes, std::vector<PackedTri> &tris, std::vector<PackedShade> &shade, std::vector<PackedUV> &uvs, std::vector<LightTri> &lightTris, std::vector<ModelDesc> &descs) {
-    const std::vector<float> &info = ctx->host[RT_SLOT_MODEL_INFO];
-    const std::vector<float> &mdl = ctx->host[RT_SLOT_MODELS];
-    const std::vector<float> &mats = ctx->host[RT_SLOT_MATERIALS];
-    const std::vector<float> &tex = ctx->host[RT_SLOT_TEXTURES];
-    const std::vector<float> &obj = ctx->host[RT_SLOT_OBJECTS];
-    const int materialCount = (int)(mats.size() / kMaterialWords);
-    if (materialCount < 1) return RT_ERR_SCENE;   // material 0 must exist
-
-    // Texture references of every material must point at a complete texture.
-    for (int m = 0; m < materialCount; ++m) {
-        for (int k = 0; k < 6; ++k) {
-            int ref = f2i(mats[(size_t)m * kMaterialWords + k]);
-            if (ref == -1) continue;
-            if (ref < 0 || (size_t)ref + 5 > tex.size()) return RT_ERR_SCENE;
-            int w = f2i(tex[ref]), h = f2i(tex[ref + 1]), c = f2i(tex[ref + 2]);
-            if (w <= 0 || h <= 0 || c <= 0 || (size_t)ref + 5 + (size_t)w * h * c > tex.size()) return RT_ERR_SCENE;
-        }
-    }
-
-    // Primitive stream: objectCount well-formed records.  Where each starts is kept for the shading kernels, which
-    // would otherwise walk the variable-length records up to the one that was hit.
-    ctx->hPrimAt.clear();
-    {
-        size_t at = 0;
-        for (int i = 0; i < ctx->objectCount; ++i) {
-            if (at + 2 > obj.size()) return RT_ERR_SCENE;
-            int type = f2i(obj[at]), material = f2i(obj[at + 1]);
-            if (material < 0 || material >= materialCount) return RT_ERR_SCENE;
-            ctx->hPrimAt.push_back((int32_t)at);
-            at += 2;
-            at += (type == 0) ? 4 : (type == 1) ? 10 : (type == 2) ? 18 : 0;
-            if (type < 0 || type > 2 || at > obj.size()) return RT_ERR_SCENE;
-        }
-    }
-
-    ctx->maxTreeDepth = 0;
-    ctx->hasAlphaTest = false;
-    if ((size_t)ctx->modelsCount * 4 > info.size()) return RT_ERR_SCENE;
-    if (ctx->lightSourcesCount < 0 || ctx->lightSourcesCount > ctx->modelsCount) return RT_ERR_SCENE;
-    descs.resize((size_t)ctx->modelsCount);
-
-    for (int m = 0; m < ctx->modelsCount; ++m) {
-        ModelDesc d{};
-        d.identifiersCount = f2i(info[(size_t)m * 4 + 0]);
-        d.lightSourcesCount = f2i(info[(size_t)m * 4 + 1]);
-        d.nodesCount = f2i(info[(size_t)m * 4 + 2]);
-        d.lightBase = f2i(info[(size_t)m * 4 + 3]);
-        if (d.identifiersCount < 0 || d.lightSourcesCount < 0 || d.nodesCount < 0 || d.lightBase < 0) return RT_ERR_SCENE;
-        if (m < ctx->lightSourcesCount && d.lightSourcesCount <= 0) return RT_ERR_SCENE;  // light models come first
-        // Section ends in 64 bits: counts are caller data, and a product such as identifiersCount * 5
-        // must not wrap into a small offset that passes the range test.
-        const int64_t nodeBase = (int64_t)d.lightBase + (int64_t)d.lightSourcesCount * kIdentWords;
-        const int64_t identBase = nodeBase + (int64_t)d.nodesCount * kNodeWords;
-        const int64_t vertBase = identBase + (int64_t)d.identifiersCount * kIdentWords;
-        if (vertBase > (int64_t)mdl.size() || vertBase > 0x7fffffff) return RT_ERR_SCENE;   // every section lies inside the stream
-        d.nodeBase = (int32_t)nodeBase;
-        d.identBase = (int32_t)identBase;
-        d.vertBase = (int32_t)vertBase;
-        d.triBase = (int32_t)tris.size();
-        // Leaf references keep the triangle index in 29 bits below the sign.
-        if (tris.size() + (size_t)d.identifiersCount >= (1u << 29)) return RT_ERR_SCENE;
-        const int vertexCapacity = (int)((mdl.size() - (size_t)d.vertBase) / 8);
-
-        auto checkIdent = [&](int wordAt) -> bool {
-            for (int k = 0; k < 3; ++k) {
-                int vi = f2i(mdl[(size_t)wordAt + k]);
-                if (vi < 0 || vi >= vertexCapacity) return false;
-            }
-            int mat = f2i(mdl[(size_t)wordAt + 3]);
-            return mat >= 0 && mat < materialCount;
-        };
-        d.lightTriBase = (int32_t)lightTris.size();
-        for (int l = 0; l < d.lightSourcesCount; ++l) {
-            LightTri lt{};
-            float *corner[3] = {lt.p0, lt.p1, lt.p2};
-            for (int k = 0; k < 3; ++k) {
-                int vi = f2i(mdl[(size_t)d.lightBase + (size_t)l * kIdentWords + k]);
-                if (vi < 0 || vi >= vertexCapacity) return RT_ERR_SCENE;
-                for (int c = 0; c < 3; ++c) corner[k][c] = mdl[(size_t)d.vertBase + (size_t)vi * 8 + (size_t)c];
-            }
-            const V3 p0 = v3(lt.p0[0], lt.p0[1], lt.p0[2]), p1 = v3(lt.p1[0], lt.p1[1], lt.p1[2]), p2 = v3(lt.p2[0], lt.p2[1], lt.p2[2]);
-            lt.area = 0.5f * length(cross(p1 - p0, p2 - p0));   // as sampleRandomPointFromLightSouces computes it, src/RayScene.cpp:900-935
-            lightTris.push_back(lt);
-        }
-
-        // Triangles in identifier (leaf) order.
-        for (int t = 0; t < d.identifiersCount; ++t) {
-            int at = d.identBase + t * kIdentWords;
-            if (!checkIdent(at)) return RT_ERR_SCENE;
-            int idx[3] = {f2i(mdl[at]), f2i(mdl[at + 1]), f2i(mdl[at + 2])};
-            int material = f2i(mdl[at + 3]);
-            bool hasTextures = mdl[at + 4] != 0.0f;
-            const float *A = &mdl[(size_t)d.vertBase + (size_t)idx[0] * 8];
-            const float *B = &mdl[(size_t)d.vertBase + (size_t)idx[1] * 8];
-            const float *C = &mdl[(size_t)d.vertBase + (size_t)idx[2] * 8];
-            PackedTri pt;
-            for (int k = 0; k < 3; ++k) {
-                pt.a[k] = A[k];
-                pt.ab[k] = B[k] - A[k];
-                pt.ac[k] = C[k] - A[k];
-            }
-            pt.material = material;
-            pt.model = m;
-            pt.ident = t;
-            if (hasTextures) {
-                int baseColor = f2i(mats[(size_t)material * kMaterialWords + 1]);
-                float alphaCut = mats[(size_t)material * kMaterialWords + 20];
-                if (baseColor != -1 && alphaCut > 0.0f) {
-                    pt.model |= kTriAlphaTest;
-                    ctx->hasAlphaTest = true;
-                }
-            }
-            tris.push_back(pt);
-            PackedShade ps{};
-            for (int k = 0; k < 3; ++k) {
-                ps.n0[k] = A[3 + k];
-                ps.n1[k] = B[3 + k];
-                ps.n2[k] = C[3 + k];
-            }
-            // (the same single-precision operations, in the same order, as the kernels would run on every hit)
-            const V3 geometric = cross(v3(pt.ab[0], pt.ab[1], pt.ab[2]), v3(pt.ac[0], pt.ac[1], pt.ac[2]));
-            ps.geometric[0] = geometric.x; ps.geometric[1] = geometric.y; ps.geometric[2] = geometric.z;
-            ps.area = 0.5f * length(geometric);
-            ps.material = material;
-            ps.model = m;
-            ps.hasTextures = hasTextures ? 1 : 0;
-            shade.push_back(ps);
-            PackedUV pu{};
-            for (int k = 0; k < 2; ++k) {
-                pu.uv0[k] = A[6 + k];
-                pu.uv1[k] = B[6 + k];
-                pu.uv2[k] = C[6 + k];
-            }
-            uvs.push_back(pu);
-        }
-
-        // Inner nodes get consecutive packed indices in original node order.
-        std::vector<int32_t> packedIndex((size_t)d.nodesCount, -1);
-        const int32_t innerBase = (int32_t)nodes.size();
-        int32_t innerCount = 0;
-        auto nodeWord = [&](int n, int w) { return mdl[(size_t)d.nodeBase + (size_t)n * kNodeWords + w]; };
-        for (int n = 0; n < d.nodesCount; ++n)
-            if (nodeWord(n, 8) == 0.0f) packedIndex[(size_t)n] = innerBase + innerCount++;
-        auto childRef = [&](int n, int32_t &ref) -> bool {
-            if (n < 0 || n >= d.nodesCount) return false;
-            if (nodeWord(n, 8) != 0.0f) {
-                int first = f2i(nodeWord(n, 6)), last = f2i(nodeWord(n, 7));
-                int count = last - first;
-                if (first < 0 || count < 0 || count > 3 || last > d.identifiersCount) return false;
-                ref = ~(int32_t)((((uint32_t)(d.triBase + first)) << 2) | (uint32_t)count);
-            } else {
-                ref = packedIndex[(size_t)n];
-            }
-            return true;
-        };
-        nodes.resize((size_t)innerBase + (size_t)innerCount);
-        // A tree, not a graph: children come after their parent (no cycles) and every node has at
-        // most one parent (a node shared by two parents would make a 32-level graph 2^32 nodes
-        // large for anything that walks it as a tree).
-        std::vector<char> hasParent((size_t)d.nodesCount, 0);
-        for (int n = 0; n < d.nodesCount; ++n) {
-            if (nodeWord(n, 8) != 0.0f) continue;
-            int l = f2i(nodeWord(n, 6)), r = f2i(nodeWord(n, 7));
-            if (l <= n || r <= n || l >= d.nodesCount || r >= d.nodesCount || l == r) return RT_ERR_SCENE;
-            if (hasParent[(size_t)l] || hasParent[(size_t)r]) return RT_ERR_SCENE;
-            hasParent[(size_t)l] = hasParent[(size_t)r] = 1;
-            PackedNode pn{};
-            if (!childRef(l, pn.left) || !childRef(r, pn.right)) return RT_ERR_SCENE;
-            for (int k = 0; k < 3; ++k) {
-                pn.lmin[k] = nodeWord(l, k);
-                pn.lmax[k] = nodeWord(l, 3 + k);
-                pn.rmin[k] = nodeWord(r, k);
-                pn.rmax[k] = nodeWord(r, 3 + k);
-            }
-            nodes[(size_t)packedIndex[(size_t)n]] = pn;
-        }
-        if (d.nodesCount > 0) {
-            if (!childRef(0, d.rootRef)) return RT_ERR_SCENE;
-            // Depth bound: the traversal stack holds at most depth entries.
-            std::vector<std::pair<int, int>> todo{{0, 1}};
-            int maxDepth = 0;
-            while (!todo.empty()) {
-                auto [n, depth] = todo.back();
-                todo.pop_back();
-                maxDepth = std::max(maxDepth, depth);
-                if (nodeWord(n, 8) != 0.0f) continue;
-                todo.push_back({f2i(nodeWord(n, 6)), depth + 1});
-                todo.push_back({f2i(nodeWord(n, 7)), depth + 1});
-            }
-            if (maxDepth > kStackDepth) return RT_ERR_SCENE;
-            ctx->maxTreeDepth = std::max(ctx->maxTreeDepth, maxDepth);
-        }
-        descs[(size_t)m] = d;
-    }
-    return RT_OK;
-}
-
-// RT_COMMIT_TIMING=1: prints the host time since `since` under the name `what`, and restarts the clock.
-void commitLap(const char *what, std::chrono::steady_clock::time_point &since) {
-    static const bool on = std::getenv("RT_COMMIT_TIMING") != nullptr;
-    const auto now = std::chrono::steady_clock::now();
-    if (on) std::fprintf(stderr, "rt_commit_scene:   %-26s %7.1f ms\n", what, std::chrono::duration<double, std::milli>(now - since).count());
-    since = now;
-}
-
-// Host threads for building trees at commit: RT_BUILD_THREADS, else the machine's, at most 16.
-int buildThreads() {
-    if (const char *env = std::getenv("RT_BUILD_THREADS")) return std::min(std::max(std::atoi(env), 1), 64);
-    return (int)std::min(std::max(std::thread::hardware_concurrency(), 1u), 16u);
-}
-
-// Joins every thread it holds when it goes out of scope, so that an exception thrown while threads
-// are running (an allocation failure in the spawning loop or in the caller's own share of the work)
-// unwinds past joined threads instead of ending the process in ~thread.
-struct ThreadGroup {
-    std::vector<std::thread> threads;
-    explicit ThreadGroup(size_t expected) { threads.reserve(expected); }
-    ~ThreadGroup() { join(); }
-    void join() {
-        for (std::thread &t : threads)
-            if (t.joinable()) t.join();
-    }
-    // False when the system has no thread to give: the caller does that piece itself.
-    template <typename Fn, typename... Args> bool spawn(Fn &&fn, Args &&...args) {
-        try {
-            threads.emplace_back(std::forward<Fn>(fn), std::forward<Args>(args)...);
-            return true;
-        } catch (const std::system_error &) {
-            return false;
-        }
-    }
-};
-
-// Binary tree over one model's triangles by binned surface-area splits (16 bins per axis on the
-// triangle centres), for RT_OPT_WIDE_BVH 2 and 3.  Nodes are emitted (root first) through `emit(box,
-// left, right, leafRef, leaf)` with child numbers relative to the model's first node; leaves hold one
-// or two triangles (three where equal centres leave no split).  `wtris` receives the model's packed
-// triangles in leaf order.  Boxes are the exact bounds of the vertices; the
-// margin the device arithmetic needs is added when they are quantised.
-template <typename Emit>
-bool sahTree(const std::vector<float> &mdl, const ModelDesc &d, const std::vector<PackedTri> &tris, std::vector<PackedTri> &wtris, Emit emit) {
-    const int T = d.identifiersCount;
-    auto mark = std::chrono::steady_clock::now();
-    struct Prim { float box[6]; float centre[3]; };
-    std::vector<Prim> prims((size_t)T);
-    for (int t = 0; t < T; ++t) {
-        const int at = d.identBase + t * kIdentWords;
-        Prim &p = prims[(size_t)t];
-        for (int k = 0; k < 3; ++k) { p.box[k] = INFINITY; p.box[3 + k] = -INFINITY; }
-        for (int c = 0; c < 3; ++c) {
-            const float *v = &mdl[(size_t)d.vertBase + (size_t)f2i(mdl[(size_t)at + c]) * 8];
-            for (int k = 0; k < 3; ++k) {
-                if (!(std::fabs(v[k]) <= 1e15f)) return false;
-                p.box[k] = std::min(p.box[k], v[k]);
-                p.box[3 + k] = std::max(p.box[3 + k], v[k]);
-            }
-        }
-        for (int k = 0; k < 3; ++k) p.centre[k] = 0.5f * p.box[k] + 0.5f * p.box[3 + k];
-    }
-    std::vector<int32_t> order((size_t)T);
-    for (int t = 0; t < T; ++t) order[(size_t)t] = t;
-    if (T >= 65536) commitLap("triangle bounds", mark);
-
-    struct Node { float box[6]; int32_t left, right, lo, hi; };
-    auto bounds = [&](int lo, int hi, float *box) {
-        for (int k = 0; k < 3; ++k) { box[k] = INFINITY; box[3 + k] = -INFINITY; }
-        for (int i = lo; i < hi; ++i)
-            for (int k = 0; k < 3; ++k) {
-                box[k] = std::min(box[k], prims[(size_t)order[(size_t)i]].box[k]);
-                box[3 + k] = std::max(box[3 + k], prims[(size_t)order[(size_t)i]].box[3 + k]);
-            }
-    };
-    auto halfArea = [](const float *b) {
-        const double ex = (double)b[3] - b[0], ey = (double)b[4] - b[1], ez = (double)b[5] - b[2];
-        return ex * ey + ey * ez + ez * ex;
-    };
-    constexpr int kBins = 16;
-    const int workers = T >= 65536 ? buildThreads() : 1;
-    // Runs fn(part, a, b) over `parts` equal pieces of [lo, hi), piece 0 on this thread.
-    auto forked = [](int parts, int lo, int hi, auto fn) {
-        const long long count = hi - lo;
-        ThreadGroup pool((size_t)parts);
-        for (int t = 1; t < parts; ++t) {
-            const int a = lo + (int)(count * t / parts), b = lo + (int)(count * (t + 1) / parts);
-            if (!pool.spawn(fn, t, a, b)) fn(t, a, b);   // no thread to be had: do the piece here
-        }
-        fn(0, lo, lo + (int)(count / parts));
-        pool.join();
-    };
-    struct Bins {
-        int counts[3][kBins];
-        float boxes[3][kBins][6];
-        float cb[6];
-        void clear() {
-            for (int k = 0; k < 3; ++k) { cb[k] = INFINITY; cb[3 + k] = -INFINITY; }
-            for (auto &axis : counts) for (int &c : axis) c = 0;
-            for (auto &axis : boxes) for (auto &bb : axis) for (int k = 0; k < 3; ++k) { bb[k] = INFINITY; bb[3 + k] = -INFINITY; }
-        }
-    };
-    // Where to cut order[lo, hi): partitions the range and returns the first index of the right
-    // part, or -1 for a leaf.  Touches nothing outside the range.  With mayFork the scans of a long
-    // range are shared among threads; minima, maxima and counts merge exactly, so the cut is the same.
-    auto split = [&](int lo, int hi, int depth, bool mayFork) -> int {
-        const int count = hi - lo;
-        if (count <= 2) return -1;
-        const int parts = mayFork ? std::max(1, std::min(workers, count / 8192)) : 1;
-        std::vector<Bins> partial((size_t)parts);
-        for (Bins &pb : partial) pb.clear();
-        forked(parts, lo, hi, [&](int part, int a, int b) {
-            float *cb = partial[(size_t)part].cb;
-            for (int i = a; i < b; ++i)
-                for (int k = 0; k < 3; ++k) {
-                    cb[k] = std::min(cb[k], prims[(size_t)order[(size_t)i]].centre[k]);
-                    cb[3 + k] = std::max(cb[3 + k], prims[(size_t)order[(size_t)i]].centre[k]);
-                }
-        });
-        float cb[6];
-        for (int k = 0; k < 3; ++k) { cb[k] = INFINITY; cb[3 + k] = -INFINITY; }
-        for (const Bins &pb : partial)
-            for (int k = 0; k < 3; ++k) { cb[k] = std::min(cb[k], pb.cb[k]); cb[3 + k] = std::max(cb[3 + k], pb.cb[3 + k]); }
-        double extents[3];
-        for (int axis = 0; axis < 3; ++axis) extents[axis] = (double)cb[3 + axis] - cb[axis];
-        double bestCost = INFINITY;
-        int bestAxis = -1, bestBin = -1;
-        if (depth < 48) {
-            forked(parts, lo, hi, [&](int part, int a, int b) {
-                Bins &mine = partial[(size_t)part];
-                for (int i = a; i < b; ++i) {
-                    const Prim &pr = prims[(size_t)order[(size_t)i]];
-                    for (int axis = 0; axis < 3; ++axis) {
-                        if (!(extents[axis] > 0.0)) continue;
-                        int bin = (int)(kBins * (((double)pr.centre[axis] - cb[axis]) / extents[axis]));
-                        bin = std::min(std::max(bin, 0), kBins - 1);
-                        mine.counts[axis][bin]++;
-                        float *bb = mine.boxes[axis][bin];
-                        for (int k = 0; k < 3; ++k) { bb[k] = std::min(bb[k], pr.box[k]); bb[3 + k] = std::max(bb[3 + k], pr.box[3 + k]); }
-                    }
-                }
-            });
-            Bins &all = partial[0];
-            for (size_t t = 1; t < partial.size(); ++t)
-                for (int axis = 0; axis < 3; ++axis)
-                    for (int bin = 0; bin < kBins; ++bin) {
-                        all.counts[axis][bin] += partial[t].counts[axis][bin];
-                        for (int k = 0; k < 3; ++k) {
-                            all.boxes[axis][bin][k] = std::min(all.boxes[axis][bin][k], partial[t].boxes[axis][bin][k]);
-                            all.boxes[axis][bin][3 + k] = std::max(all.boxes[axis][bin][3 + k], partial[t].boxes[axis][bin][3 + k]);
-                        }
-                    }
-            for (int axis = 0; axis < 3; ++axis) {
-                if (!(extents[axis] > 0.0)) continue;
-                const int *counts = all.counts[axis];
-                float (*boxes)[6] = all.boxes[axis];
-                double rightArea[kBins];
-                int rightCount[kBins];
-                float acc[6];
-                for (int k = 0; k < 3; ++k) { acc[k] = INFINITY; acc[3 + k] = -INFINITY; }
-                int c = 0;
-                for (int bin = kBins - 1; bin > 0; --bin) {
-                    for (int k = 0; k < 3; ++k) { acc[k] = std::min(acc[k], boxes[bin][k]); acc[3 + k] = std::max(acc[3 + k], boxes[bin][3 + k]); }
-                    c += counts[bin];
-                    rightArea[bin] = c ? halfArea(acc) : 0.0;
-                    rightCount[bin] = c;
-                }
-                for (int k = 0; k < 3; ++k) { acc[k] = INFINITY; acc[3 + k] = -INFINITY; }
-                c = 0;
-                for (int bin = 0; bin < kBins - 1; ++bin) {
-                    for (int k = 0; k < 3; ++k) { acc[k] = std::min(acc[k], boxes[bin][k]); acc[3 + k] = std::max(acc[3 + k], boxes[bin][3 + k]); }
-                    c += counts[bin];
-                    if (c == 0 || rightCount[bin + 1] == 0) continue;
-                    const double cost = halfArea(acc) * c + rightArea[bin + 1] * rightCount[bin + 1];
-                    if (cost < bestCost) { bestCost = cost; bestAxis = axis; bestBin = bin; }
-                }
-            }
-        }
-        int mid = -1;
-        if (bestAxis >= 0) {
-            const double extent = (double)cb[3 + bestAxis] - cb[bestAxis];
-            auto first = order.begin() + lo, last = order.begin() + hi;
-            auto cut = std::partition(first, last, [&](int32_t t) {
-                int bin = (int)(kBins * (((double)prims[(size_t)t].centre[bestAxis] - cb[bestAxis]) / extent));
-                return std::min(std::max(bin, 0), kBins - 1) <= bestBin;
-            });
-            mid = (int)(cut - order.begin());
-        }
-        if (mid <= lo || mid >= hi) mid = count > 3 ? lo + count / 2 : -1;   // equal centres: halve, or keep three together
-        return mid;
-    };
-    // Builds the subtree over order[lo, hi) into `out` (child numbers index `out`): a node is
-    // numbered when it is taken off the stack, its left subtree follows it directly, and the
-    // parent's right link is patched when that child is numbered.  Ranges of at most `defer`
-    // triangles are not expanded but listed in `later` (with the node that stands for them).
-    struct Todo { int lo, hi, parent; bool isRight; int depth; };
-    struct Deferred { int lo, hi, depth; int32_t node; };
-    auto build = [&](int lo0, int hi0, int depth0, std::vector<Node> &out, int defer, std::vector<Deferred> *later) {
-        std::vector<Todo> todo{{lo0, hi0, -1, false, depth0}};
-        while (!todo.empty()) {
-            const Todo it = todo.back();
-            todo.pop_back();
-            const int32_t self = (int32_t)out.size();
-            out.emplace_back();
-            if (it.parent >= 0) (it.isRight ? out[(size_t)it.parent].right : out[(size_t)it.parent].left) = self;
-            Node n{};
-            n.lo = it.lo;
-            n.hi = it.hi;
-            n.left = n.right = -1;
-            if (later != nullptr && it.hi - it.lo <= defer && it.hi - it.lo > 2) {
-                later->push_back({it.lo, it.hi, it.depth, self});
-                out[(size_t)self] = n;
-                continue;
-            }
-            const int pieces = later != nullptr ? std::max(1, std::min(workers, (it.hi - it.lo) / 8192)) : 1;
-            if (pieces > 1) {   // a long range near the top: the scan is shared, minima and maxima merge exactly
-                std::vector<std::array<float, 6>> partial((size_t)pieces);
-                forked(pieces, it.lo, it.hi, [&](int part, int a, int b) { bounds(a, b, partial[(size_t)part].data()); });
-                for (int k = 0; k < 3; ++k) { n.box[k] = INFINITY; n.box[3 + k] = -INFINITY; }
-                for (const auto &pbox : partial)
-                    for (int k = 0; k < 3; ++k) { n.box[k] = std::min(n.box[k], pbox[(size_t)k]); n.box[3 + k] = std::max(n.box[3 + k], pbox[(size_t)(3 + k)]); }
-            } else {
-                bounds(it.lo, it.hi, n.box);
-            }
-            const int mid = split(it.lo, it.hi, it.depth, later != nullptr);
-            out[(size_t)self] = n;
-            if (mid > 0) {
-                todo.push_back({mid, it.hi, self, true, it.depth + 1});
-                todo.push_back({it.lo, mid, self, false, it.depth + 1});
-            }
-        }
-    };
-    // Large models: the top of the tree is cut on this thread until the ranges are small, then the
-    // ranges (disjoint parts of `order`) are built side by side and appended in range order, so the
-    // result does not depend on the number of threads.
-    std::vector<Node> nodes;
-    nodes.reserve((size_t)T);
-    if (workers <= 1) {
-        build(0, T, 0, nodes, 0, nullptr);
-    } else {
-        std::vector<Deferred> later;
-        build(0, T, 0, nodes, std::max(T / (workers * 4), 8192), &later);
-        std::vector<std::vector<Node>> parts(later.size());
-        std::atomic<size_t> next{0};
-        std::atomic<bool> failed{false};   // an allocation failure must not end the process from inside a thread
-        auto work = [&]() {
-            try {
-                for (size_t k = next.fetch_add(1); k < later.size(); k = next.fetch_add(1))
-                    build(later[k].lo, later[k].hi, later[k].depth, parts[k], 0, nullptr);
-            } catch (...) {
-                failed = true;
-            }
-        };
-        {
-            ThreadGroup pool((size_t)workers);
-            for (int w = 1; w < workers; ++w)
-                if (!pool.spawn(work)) break;   // the threads that did start, and this one, share the ranges
-            work();
-        }
-        if (failed) throw std::bad_alloc();   // reported as RT_ERR_NOMEM by the caller
-        for (size_t k = 0; k < later.size(); ++k) {
-            // the part's root takes the place of the node that stood for the range; the rest is appended
-            const int32_t shift = (int32_t)nodes.size() - 1;
-            auto moved = [&](int32_t c) { return c < 0 ? c : c + shift; };
-            const std::vector<Node> &part = parts[k];
-            Node root = part[0];
-            root.left = moved(root.left);
-            root.right = moved(root.right);
-            nodes[(size_t)later[k].node] = root;
-            for (size_t i = 1; i < part.size(); ++i) {
-                Node n = part[i];
-                n.left = moved(n.left);
-                n.right = moved(n.right);
-                nodes.push_back(n);
-            }
-        }
-    }
-    if (T >= 65536) commitLap("binary tree", mark);
-    // The triangle records in this tree's leaf order, each naming its place in `tris`; then the nodes.
-    for (int i = 0; i < T; ++i) {
-        const int32_t at = d.triBase + order[(size_t)i];
-        PackedTri pt = tris[(size_t)at];
-        pt.ident = at;
-        wtris[(size_t)d.triBase + (size_t)i] = pt;
-    }
-    for (const Node &n : nodes) {
-        const bool leaf = n.left < 0;
-        const int32_t leafRef = leaf ? ~(int32_t)((((uint32_t)(d.triBase + n.lo)) << 2) | (uint32_t)(n.hi - n.lo)) : 0;
-        emit(n.box, n.left, n.right, leafRef, leaf);
-    }
-    if (T >= 65536) commitLap("leaf-order copy + emit", mark);
-    return true;
-}
-
-// Binary trees of all models in one array, as the collapse into wide nodes reads them: box, children
-// (indices into the array), or the leaf reference.
-struct BinNode { float box[6]; int32_t left, right; int32_t leafRef; bool leaf; };
-struct BinaryTrees {
-    std::vector<BinNode> bin;
-    std::vector<std::pair<int32_t, ModelDesc *>> roots;   // root node and model of every tree that is more than one leaf
-    double reach = 0.0;                                    // largest coordinate magnitude of any root box
-};
-
-// Fills `trees` with every model's binary tree: the library's own binned-SAH tree when `rebuild` (then
-// `wtris` receives the triangle records in that tree's leaf order), else the uploaded one.  A model
-// whose tree is a single leaf gets that leaf's reference in wideRootRef and no entry in `roots`.
-int binaryTreesOfModels(rt_ctx *ctx, std::vector<ModelDesc> &descs, const std::vector<PackedTri> &tris, std::vector<PackedTri> &wtris, bool rebuild, BinaryTrees &trees) {
-    const std::vector<float> &mdl = ctx->host[RT_SLOT_MODELS];
-    std::vector<BinNode> &bin = trees.bin;
-    auto &roots = trees.roots;
-    double &reach = trees.reach;
-    // Triangles in the order of the trees walked, each naming its index in `tris` (what hit records
-    // and shading use): the uploaded order unless a model's tree is rebuilt below.
-    auto mark = std::chrono::steady_clock::now();
-    wtris = tris;
-    for (size_t i = 0; i < wtris.size(); ++i) wtris[i].ident = (int32_t)i;
-    commitLap("triangle copy", mark);
-    using Bin = BinNode;
-    for (ModelDesc &d : descs) {
-        d.wideRootRef = d.rootRef;   // a tree that is one leaf: same reference, wtris being a copy of tris there
-        if (d.nodesCount <= 0) continue;
-        if (rebuild && d.identifiersCount > 0) {
-            // The library's own tree over the model's triangles: binned surface-area splits, leaves
-            // of one or two triangles, a copy of the triangle records in its leaf order.
-            const int32_t base = (int32_t)bin.size();
-            if (!sahTree(mdl, d, tris, wtris, [&](const float *box, int32_t left, int32_t right, int32_t leafRef, bool leaf) {
-                    Bin b{};
-                    for (int k = 0; k < 6; ++k) b.box[k] = box[k];
-                    b.left = leaf ? -1 : base + left;
-                    b.right = leaf ? -1 : base + right;
-                    b.leafRef = leafRef;
-                    b.leaf = leaf;
-                    bin.push_back(b);
-                })) return RT_ERR_SCENE;
-            if (bin[(size_t)base].leaf) {
-                d.wideRootRef = bin[(size_t)base].leafRef;
-                continue;
-            }
-            roots.push_back({base, &d});
-            for (int k = 0; k < 6; ++k) reach = std::max(reach, (double)std::fabs(bin[(size_t)base].box[k]));
-            continue;
-        }
-        const int32_t base = (int32_t)bin.size();
-        bin.resize(bin.size() + (size_t)d.nodesCount);
-        for (int n = 0; n < d.nodesCount; ++n) {
-            const float *w = &mdl[(size_t)d.nodeBase + (size_t)n * kNodeWords];
-            Bin &b = bin[(size_t)base + n];
-            for (int k = 0; k < 6; ++k) b.box[k] = w[k];
-            b.leaf = w[8] != 0.0f;
-            if (b.leaf) {
-                const int first = f2i(w[6]), count = f2i(w[7]) - first;
-                b.left = b.right = -1;
-                b.leafRef = ~(int32_t)((((uint32_t)(d.triBase + first)) << 2) | (uint32_t)count);
-            } else {
-                b.left = base + f2i(w[6]);
-                b.right = base + f2i(w[7]);
-                b.leafRef = 0;
-            }
-        }
-        if (bin[(size_t)base].leaf) continue;   // rootRef already names the leaf
-        roots.push_back({base, &d});
-        for (int k = 0; k < 6; ++k) reach = std::max(reach, (double)std::fabs(bin[(size_t)base].box[k]));
-    }
-    commitLap("binary trees, all models", mark);
-    return RT_OK;
-}
-
-// Four-wide tree of every model, collapsed from the binary tree of the model stream: a node adopts
-// the children of its child with the largest box until it has four (or only leaves are left).
-// `descs` must have passed repackScene; wideRootRef receives the new tree's root.
-int buildWideNodes(rt_ctx *ctx, std::vector<ModelDesc> &descs, std::vector<WideNode> &wnodes, const std::vector<PackedTri> &tris, std::vector<PackedTri> &wtris) {
-    ctx->wideStackNeed = 0;
-    BinaryTrees trees;
-    const int treesRc = binaryTreesOfModels(ctx, descs, tris, wtris, ctx->wideBvh >= 2, trees);
-    if (treesRc != RT_OK) return treesRc;
-    std::vector<BinNode> &bin = trees.bin;
-    auto &roots = trees.roots;
-    const double reach = trees.reach;
-    auto mark = std::chrono::steady_clock::now();
-    if (roots.empty()) return RT_OK;
-    if (!(reach <= 1e15)) return RT_ERR_SCENE;   // also catches NaN
-    // Margin around every box for the rounding of the plane arithmetic on the device, whose operands
-    // are as large as the distance from the ray origin to the scene: four units in the last place of
-    // the scene's largest coordinate.
-    const double pad = std::ldexp(reach, -21);
-
-    auto leafCount = [&](int32_t n) { return (int)((~(uint32_t)bin[(size_t)n].leafRef) & 3u); };
-    auto area = [&](int32_t n) {
-        const float *b = bin[(size_t)n].box;
-        const double ex = (double)b[3] - b[0], ey = (double)b[4] - b[1], ez = (double)b[5] - b[2];
-        return ex * ey + ey * ez + ez * ex;
-    };
-    struct Item { int32_t node; int32_t wide; int held; };   // binary node to expand, its slot, entries its ancestors keep stacked
-    std::vector<Item> todo;
-    struct Family { int32_t kids[4]; int count; };   // the binary nodes a wide node's children stand for
-    std::vector<Family> families(wnodes.size());
-    for (auto &rootOf : roots) {
-        rootOf.second->wideRootRef = (int32_t)wnodes.size();
-        wnodes.emplace_back();
-        families.emplace_back();
-        todo.push_back({rootOf.first, rootOf.second->wideRootRef, 0});
-    }
-    while (!todo.empty()) {
-        const Item it = todo.back();
-        todo.pop_back();
-        int32_t kids[4] = {bin[(size_t)it.node].left, bin[(size_t)it.node].right, -1, -1};
-        int nk = 2;
-        while (nk < 4) {
-            int best = -1;
-            double bestArea = -1.0;
-            for (int i = 0; i < nk; ++i) {
-                if (bin[(size_t)kids[i]].leaf) continue;
-                const double a = area(kids[i]);
-                if (best < 0 || a > bestArea) { best = i; bestArea = a; }
-            }
-            if (best < 0) break;
-            const int32_t n = kids[best];
-            kids[best] = bin[(size_t)n].left;
-            kids[nk++] = bin[(size_t)n].right;
-        }
-        // Leaves without triangles need no slot.
-        int kept = 0;
-        for (int i = 0; i < nk; ++i)
-            if (!(bin[(size_t)kids[i]].leaf && leafCount(kids[i]) == 0)) kids[kept++] = kids[i];
-        nk = kept;
-        Family fam{{-1, -1, -1, -1}, nk};
-        int32_t refs[4] = {-1, -1, -1, -1};   // ~0: a leaf without triangles
-        const int held = it.held + std::max(nk - 1, 0);
-        ctx->wideStackNeed = std::max(ctx->wideStackNeed, held);
-        for (int i = 0; i < nk; ++i) {
-            fam.kids[i] = kids[i];
-            if (bin[(size_t)kids[i]].leaf) {
-                refs[i] = bin[(size_t)kids[i]].leafRef;
-            } else {
-                refs[i] = (int32_t)wnodes.size();
-                wnodes.emplace_back();
-                families.emplace_back();
-                todo.push_back({kids[i], refs[i], held});
-            }
-        }
-        WideNode &wn = wnodes[(size_t)it.wide];
-        wn.c0 = refs[0]; wn.c1 = refs[1]; wn.c2 = refs[2]; wn.c3 = refs[3];
-        families[(size_t)it.wide] = fam;
-    }
-    commitLap("four-wide structure", mark);
-
-    // The child boxes of every node as 8-bit plane numbers: independent per node, shared among threads.
-    std::atomic<bool> bad{false};
-    auto quantise = [&](size_t first, size_t last) {
-        for (size_t w = first; w < last; ++w) {
-            const Family &fam = families[w];
-            const int nk = fam.count;
-            const int32_t *kids = fam.kids;
-            WideNode &wn = wnodes[w];
-            for (int i = 0; i < nk; ++i)
-                for (int k = 0; k < 6; ++k)
-                    if (!(std::fabs(bin[(size_t)kids[i]].box[k]) <= 1e15f)) { bad = true; return; }
-            for (int a = 0; a < 3; ++a) {
-                double lower = 0.0, upper = 0.0;
-                for (int i = 0; i < nk; ++i) {
-                    const double mn = bin[(size_t)kids[i]].box[a], mx = bin[(size_t)kids[i]].box[3 + a];
-                    if (mn > mx) { bad = true; return; }
-                    if (i == 0 || mn < lower) lower = mn;
-                    if (i == 0 || mx > upper) upper = mx;
-                }
-                float o = (float)(lower - pad);
-                if ((double)o > lower - pad) o = std::nextafterf(o, -INFINITY);
-                const double extent = (upper + pad) - (double)o;
-                int e = -60;
-                if (extent > 0.0) e = std::max(-60, (int)std::ceil(std::log2(extent / 255.0)));
-                for (;; ++e) {
-                    const double step = std::ldexp(1.0, e);
-                    bool fits = true;
-                    uint32_t wlo = 0, whi = 0;
-                    for (int i = 0; i < 4 && fits; ++i) {
-                        uint32_t qlo = 255, qhi = 0;   // unused slot: inverted
-                        if (i < nk) {
-                            const double mn = (double)bin[(size_t)kids[i]].box[a] - pad, mx = (double)bin[(size_t)kids[i]].box[3 + a] + pad;
-                            long ql = (long)std::floor((mn - (double)o) / step), qh = (long)std::ceil((mx - (double)o) / step);
-                            ql = std::max(0l, std::min(ql, 255l));
-                            while (ql > 0 && (double)o + (double)ql * step > mn) --ql;
-                            qh = std::max(qh, 0l);
-                            while (qh <= 255 && (double)o + (double)qh * step < mx) ++qh;
-                            if (qh > 255) { fits = false; break; }
-                            qlo = (uint32_t)ql;
-                            qhi = (uint32_t)qh;
-                        }
-                        wlo |= qlo << (8 * i);
-                        whi |= qhi << (8 * i);
-                    }
-                    if (fits) {
-                        wn.o[a] = o;
-                        wn.s[a] = (float)step;
-                        wn.lo[a] = wlo;
-                        wn.hi[a] = whi;
-                        break;
-                    }
-                }
-            }
-        }
-    };
-    {
-        const size_t total = wnodes.size();
-        const int workers = total >= 32768 ? buildThreads() : 1;
-        ThreadGroup pool((size_t)workers);
-        for (int t = 1; t < workers; ++t) {
-            const size_t first = total * (size_t)t / (size_t)workers, last = total * (size_t)(t + 1) / (size_t)workers;
-            if (!pool.spawn(quantise, first, last)) quantise(first, last);
-        }
-        quantise(0, total / (size_t)workers);
-        pool.join();
-    }
-    if (bad) return RT_ERR_SCENE;
-    commitLap("child boxes to 8 bits", mark);
-    return RT_OK;
-}
-
-// Re-packs the leaves of the four-wide trees as triangle pairs (TriPair) and rewrites every leaf
-// reference, in the nodes and in the models' roots, from (first triangle, triangles) to (first pair, pairs).
-void pairLeaves(std::vector<WideNode> &wnodes, std::vector<ModelDesc> &descs, const std::vector<PackedTri> &wtris, std::vector<TriPair> &wpairs) {
-    wpairs.clear();
-    wpairs.reserve(wtris.size() * 2 / 3 + 1);
-    auto paired = [&](int32_t ref) -> int32_t {
-        if (ref >= 0) return ref;
-        const uint32_t code = ~(uint32_t)ref, first = code >> 2, count = code & 3u;
-        if (count == 0u) return ref;
-        const uint32_t at = (uint32_t)wpairs.size(), pairs = (count + 1u) / 2u;
-        for (uint32_t p = 0; p < pairs; ++p) {
-            TriPair tp;
-            std::memset(&tp, 0, sizeof tp);
-            tp.ident[0] = tp.ident[1] = (int32_t)kMiss;
-            for (uint32_t h = 0; h < 2u && 2u * p + h < count; ++h) {
-                const PackedTri &t = wtris[(size_t)first + 2u * p + h];
-                tp.ax[h] = t.a[0]; tp.ay[h] = t.a[1]; tp.az[h] = t.a[2];
-                tp.abx[h] = t.ab[0]; tp.aby[h] = t.ab[1]; tp.abz[h] = t.ab[2];
-                tp.acx[h] = t.ac[0]; tp.acy[h] = t.ac[1]; tp.acz[h] = t.ac[2]; tp.ident[h] = t.ident;
-            }
-            wpairs.push_back(tp);
-        }
-        return ~(int32_t)((at << 2) | pairs);
-    };
-    for (WideNode &wn : wnodes) {
-        wn.c0 = paired(wn.c0); wn.c1 = paired(wn.c1); wn.c2 = paired(wn.c2); wn.c3 = paired(wn.c3);
-    }
-    for (ModelDesc &d : descs)
-        if (d.nodesCount > 0) d.wideRootRef = paired(d.wideRootRef);
-}
-
-// Eight-wide tree of every model (RT_OPT_WIDE_BVH 4), collapsed from the library's binary trees: a
-// node adopts the children of its child with the largest box until it has eight.  Layout and child
-// encoding: Wide8Node in rt_device.h.  The inner children of a node get consecutive node numbers and
-// the triangles of its leaf children consecutive places in `w8tris`, both in slot order; slots are
-// dealt so that a child lying towards (+x, +y, +z) of the node's centre sits in the slot whose number
-// has those bits set, which lets the device visit children front to back by slot number alone.
-int buildWide8(rt_ctx *ctx, std::vector<ModelDesc> &descs, std::vector<Wide8Node> &w8, const std::vector<PackedTri> &tris, std::vector<PackedTri> &w8tris) {
-    ctx->wideStackNeed = 0;
-    BinaryTrees trees;
-    std::vector<PackedTri> leafTris;   // in the binary trees' leaf order
-    const int treesRc = binaryTreesOfModels(ctx, descs, tris, leafTris, true, trees);
-    if (treesRc != RT_OK) return treesRc;
-    const std::vector<BinNode> &bin = trees.bin;
-    auto mark = std::chrono::steady_clock::now();
-    if (!(trees.reach <= 1e15)) return RT_ERR_SCENE;   // also catches NaN
-    const double pad = std::ldexp(trees.reach, -21);   // see buildWideNodes
-
-    w8tris.clear();
-    w8tris.reserve(tris.size());
-    auto leafFirst = [&](int32_t n) { return (~(uint32_t)bin[(size_t)n].leafRef) >> 2; };
-    auto leafCount = [&](int32_t n) { return (int)((~(uint32_t)bin[(size_t)n].leafRef) & 3u); };
-    // Appends the triangles of a leaf reference (into leafTris) and returns the reference into w8tris.
-    auto moveLeaf = [&](int32_t ref) -> int32_t {
-        const uint32_t code = ~(uint32_t)ref, first = code >> 2, count = code & 3u;
-        const uint32_t at = (uint32_t)w8tris.size();
-        for (uint32_t k = 0; k < count; ++k) w8tris.push_back(leafTris[(size_t)first + k]);
-        return ~(int32_t)((at << 2) | count);
-    };
-    // Models whose tree is one leaf keep a leaf reference as their root; a leaf without triangles
-    // (and a model without triangles) has nothing to walk.
-    for (ModelDesc &d : descs) {
-        if (d.nodesCount <= 0) continue;
-        bool hasTree = false;
-        for (const auto &r : trees.roots) hasTree = hasTree || r.second == &d;
-        if (hasTree) continue;
-        const uint32_t count = (~(uint32_t)d.wideRootRef) & 3u;
-        d.wideRootRef = (d.wideRootRef < 0 && count > 0) ? moveLeaf(d.wideRootRef) : kNoRoot;
-    }
-    auto area = [&](int32_t n) {
-        const float *b = bin[(size_t)n].box;
-        const double ex = (double)b[3] - b[0], ey = (double)b[4] - b[1], ez = (double)b[5] - b[2];
-        return ex * ey + ey * ez + ez * ex;
-    };
-    struct Family { int32_t kids[8]; };   // binary node standing behind each slot, -1 = empty
-    std::vector<Family> families;
-    struct Item { int32_t node; uint32_t wide; int depth; };
-    std::vector<Item> todo;
-    auto newNode = [&]() -> uint32_t {
-        w8.emplace_back();
-        families.push_back(Family{{-1, -1, -1, -1, -1, -1, -1, -1}});
-        return (uint32_t)(w8.size() - 1);
-    };
-    for (auto &rootOf : trees.roots) {
-        const uint32_t root = newNode();
-        rootOf.second->wideRootRef = (int32_t)root;
-        todo.push_back({rootOf.first, root, 0});
-    }
-    while (!todo.empty()) {
-        const Item it = todo.back();
-        todo.pop_back();
-        ctx->wideStackNeed = std::max(ctx->wideStackNeed, it.depth);   // one stack entry per ancestor at most
-        int32_t kids[8] = {bin[(size_t)it.node].left, bin[(size_t)it.node].right, -1, -1, -1, -1, -1, -1};
-        int nk = 2;
-        while (nk < 8) {
-            int best = -1;
-            double bestArea = -1.0;
-            for (int i = 0; i < nk; ++i) {
-                if (bin[(size_t)kids[i]].leaf) continue;
-                const double a = area(kids[i]);
-                if (best < 0 || a > bestArea) { best = i; bestArea = a; }
-            }
-            if (best < 0) break;
-            const int32_t n = kids[best];
-            kids[best] = bin[(size_t)n].left;
-            kids[nk++] = bin[(size_t)n].right;
-        }
-        int kept = 0;
-        for (int i = 0; i < nk; ++i)
-            if (!(bin[(size_t)kids[i]].leaf && leafCount(kids[i]) == 0)) kids[kept++] = kids[i];
-        nk = kept;
-        // Slots: greedily the (child, slot) pair with the largest projection of the child's centre
-        // (relative to the centre of all children) on the slot's diagonal, until every child sits.
-        double centre[3] = {0.0, 0.0, 0.0}, lo[3], hi[3];
-        for (int a = 0; a < 3; ++a) { lo[a] = INFINITY; hi[a] = -INFINITY; }
-        for (int i = 0; i < nk; ++i)
-            for (int a = 0; a < 3; ++a) {
-                lo[a] = std::min(lo[a], (double)bin[(size_t)kids[i]].box[a]);
-                hi[a] = std::max(hi[a], (double)bin[(size_t)kids[i]].box[3 + a]);
-            }
-        for (int a = 0; a < 3; ++a) centre[a] = 0.5 * (lo[a] + hi[a]);
-        double cost[8][8];
-        for (int i = 0; i < nk; ++i) {
-            double rel[3];
-            for (int a = 0; a < 3; ++a) rel[a] = 0.5 * ((double)bin[(size_t)kids[i]].box[a] + (double)bin[(size_t)kids[i]].box[3 + a]) - centre[a];
-            for (int sl = 0; sl < 8; ++sl) cost[i][sl] = ((sl & 1) ? rel[0] : -rel[0]) + ((sl & 2) ? rel[1] : -rel[1]) + ((sl & 4) ? rel[2] : -rel[2]);
-        }
-        Family fam{{-1, -1, -1, -1, -1, -1, -1, -1}};
-        bool seated[8] = {false, false, false, false, false, false, false, false};
-        for (int round = 0; round < nk; ++round) {
-            int bi = -1, bs = -1;
-            for (int i = 0; i < nk; ++i) {
-                if (seated[i]) continue;
-                for (int sl = 0; sl < 8; ++sl)
-                    if (fam.kids[sl] < 0 && (bi < 0 || cost[i][sl] > cost[bi][bs])) { bi = i; bs = sl; }
-            }
-            seated[bi] = true;
-            fam.kids[bs] = kids[bi];
-        }
-        Wide8Node wn{};
-        uint32_t imask = 0, triCount = 0;
-        uint8_t meta[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        const uint32_t triBase = (uint32_t)w8tris.size();
-        for (int sl = 0; sl < 8; ++sl) {
-            const int32_t kid = fam.kids[sl];
-            if (kid < 0) continue;
-            if (bin[(size_t)kid].leaf) {
-                const int count = leafCount(kid);
-                meta[sl] = (uint8_t)((((1u << count) - 1u) << 5) | triCount);
-                for (int k = 0; k < count; ++k) w8tris.push_back(leafTris[(size_t)leafFirst(kid) + (size_t)k]);
-                triCount += (uint32_t)count;
-            } else {
-                meta[sl] = (uint8_t)(0x38u + (uint32_t)sl);   // one bit, at place 24 + slot
-                imask |= 1u << sl;
-            }
-        }
-        wn.childBase = (uint32_t)w8.size();
-        wn.triBase = triBase;
-        wn.meta[0] = (uint32_t)meta[0] | ((uint32_t)meta[1] << 8) | ((uint32_t)meta[2] << 16) | ((uint32_t)meta[3] << 24);
-        wn.meta[1] = (uint32_t)meta[4] | ((uint32_t)meta[5] << 8) | ((uint32_t)meta[6] << 16) | ((uint32_t)meta[7] << 24);
-        wn.expImask = imask << 24;
-        // inner children: consecutive numbers in slot order; expanded in that order too (depth first)
-        std::vector<Item> mine;
-        for (int sl = 0; sl < 8; ++sl) {
-            const int32_t kid = fam.kids[sl];
-            if (kid < 0 || bin[(size_t)kid].leaf) continue;
-            const uint32_t child = newNode();
-            mine.push_back({kid, child, it.depth + 1});
-        }
-        for (size_t k = mine.size(); k-- > 0;) todo.push_back(mine[k]);
-        w8[(size_t)it.wide] = wn;
-        families[(size_t)it.wide] = fam;
-    }
-    commitLap("eight-wide structure", mark);
-
-    // Child boxes as 8-bit plane numbers on a power-of-two grid per axis, rounded outwards.
-    std::atomic<bool> bad{false};
-    auto quantise = [&](size_t first, size_t last) {
-        for (size_t w = first; w < last; ++w) {
-            const int32_t *kids = families[w].kids;
-            Wide8Node &wn = w8[w];
-            for (int a = 0; a < 3; ++a) {
-                double lower = 0.0, upper = 0.0;
-                bool any = false;
-                for (int i = 0; i < 8; ++i) {
-                    if (kids[i] < 0) continue;
-                    const double mn = bin[(size_t)kids[i]].box[a], mx = bin[(size_t)kids[i]].box[3 + a];
-                    if (!(std::fabs(mn) <= 1e15) || !(std::fabs(mx) <= 1e15) || mn > mx) { bad = true; return; }
-                    if (!any || mn < lower) lower = mn;
-                    if (!any || mx > upper) upper = mx;
-                    any = true;
-                }
-                float o = (float)(lower - pad);
-                if ((double)o > lower - pad) o = std::nextafterf(o, -INFINITY);
-                const double extent = (upper + pad) - (double)o;
-                int e = -60;
-                if (extent > 0.0) e = std::max(-60, (int)std::ceil(std::log2(extent / 255.0)));
-                for (;; ++e) {
-                    const double step = std::ldexp(1.0, e);
-                    bool fits = true;
-                    uint32_t wlo[2] = {0, 0}, whi[2] = {0, 0};
-                    for (int i = 0; i < 8 && fits; ++i) {
-                        uint32_t qlo = 255, qhi = 0;   // unused slot: inverted
-                        if (kids[i] >= 0) {
-                            const double mn = (double)bin[(size_t)kids[i]].box[a] - pad, mx = (double)bin[(size_t)kids[i]].box[3 + a] + pad;
-                            long ql = (long)std::floor((mn - (double)o) / step), qh = (long)std::ceil((mx - (double)o) / step);
-                            ql = std::max(0l, std::min(ql, 255l));
-                            while (ql > 0 && (double)o + (double)ql * step > mn) --ql;
-                            qh = std::max(qh, 0l);
-                            while (qh <= 255 && (double)o + (double)qh * step < mx) ++qh;
-                            if (qh > 255) { fits = false; break; }
-                            qlo = (uint32_t)ql;
-                            qhi = (uint32_t)qh;
-                        }
-                        wlo[i >> 2] |= qlo << (8 * (i & 3));
-                        whi[i >> 2] |= qhi << (8 * (i & 3));
-                    }
-                    if (fits) {
-                        if (e + 127 < 1 || e + 127 > 254) { bad = true; return; }
-                        wn.o[a] = o;
-                        wn.expImask |= (uint32_t)(e + 127) << (8 * a);
-                        wn.lo[a][0] = wlo[0]; wn.lo[a][1] = wlo[1];
-                        wn.hi[a][0] = whi[0]; wn.hi[a][1] = whi[1];
-                        break;
-                    }
-                }
-            }
-        }
-    };
-    {
-        const size_t total = w8.size();
-        const int workers = total >= 32768 ? buildThreads() : 1;
-        ThreadGroup pool((size_t)workers);
-        for (int t = 1; t < workers; ++t) {
-            const size_t first = total * (size_t)t / (size_t)workers, last = total * (size_t)(t + 1) / (size_t)workers;
-            if (!pool.spawn(quantise, first, last)) quantise(first, last);
-        }
-        quantise(0, total / (size_t)workers);
-        pool.join();
-    }
-    if (bad) return RT_ERR_SCENE;
-    if (w8tris.size() >= (1u << 29) || w8.size() >= (1u << 30)) return RT_ERR_SCENE;
-    commitLap("child boxes to 8 bits", mark);
-    return RT_OK;
-}
+// (validation and re-pack of the uploaded streams, the library's own trees and their collapse into wide nodes: rt_commit.cpp)
 
 // (Re)allocates every per-path buffer for `want` paths.  ctx->P is zero while the set is incomplete,
 // so a failed attempt can never leave a capacity that some buffer does not have.
@@ -1438,52 +471,9 @@ int runBatch(rt_ctx *ctx, const Batch &bt) {
     return RT_OK;
 }
 
-// RCCL is bound at run time so that the library has no link dependency on it: only a caller
-// that shards over several GPUs from C/C++ (no torch.distributed around) ever loads it.
-struct Rccl {
-    void *lib = nullptr;
-    ncclResult_t (*getUniqueId)(ncclUniqueId *) = nullptr;
-    ncclResult_t (*commInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
-    ncclResult_t (*commDestroy)(ncclComm_t) = nullptr;
-    ncclResult_t (*reduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
-    ncclResult_t (*allReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
-    const char *(*errorString)(ncclResult_t) = nullptr;
-};
-
-Rccl *rccl() {
-    static Rccl api;
-    static bool tried = false;
-    if (!tried) {
-        tried = true;
-        void *lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
-        if (lib == nullptr) lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
-        if (lib != nullptr) {
-            api.getUniqueId = reinterpret_cast<decltype(api.getUniqueId)>(dlsym(lib, "ncclGetUniqueId"));
-            api.commInitRank = reinterpret_cast<decltype(api.commInitRank)>(dlsym(lib, "ncclCommInitRank"));
-            api.commDestroy = reinterpret_cast<decltype(api.commDestroy)>(dlsym(lib, "ncclCommDestroy"));
-            api.reduce = reinterpret_cast<decltype(api.reduce)>(dlsym(lib, "ncclReduce"));
-            api.allReduce = reinterpret_cast<decltype(api.allReduce)>(dlsym(lib, "ncclAllReduce"));
-            api.errorString = reinterpret_cast<decltype(api.errorString)>(dlsym(lib, "ncclGetErrorString"));
-            if (api.getUniqueId && api.commInitRank && api.commDestroy && api.reduce && api.allReduce && api.errorString) api.lib = lib;
-        }
-    }
-    return api.lib != nullptr ? &api : nullptr;
-}
-
-#define RT_NCCL(ctx, api, call)                                                               \
-    do {                                                                                      \
-        ncclResult_t r_ = (call);                                                             \
-        if (r_ != ncclSuccess) {                                                              \
-            (ctx)->hipError = std::string(#call) + ": " + (api)->errorString(r_);             \
-            return RT_ERR_HIP;                                                                \
-        }                                                                                     \
-    } while (0)
-
 void closeComm(rt_ctx *ctx) {
-    if (ctx->comm != nullptr) {
-        if (Rccl *api = rccl()) api->commDestroy(static_cast<ncclComm_t>(ctx->comm));
-        ctx->comm = nullptr;
-    }
+    rtcomm::destroy(ctx->comm);
+    ctx->comm = nullptr;
     if (ctx->dFrameCount != nullptr) {
         hipFree(ctx->dFrameCount);
         ctx->dFrameCount = nullptr;
@@ -1508,30 +498,14 @@ int noThrow(Body body) {
 
 extern "C" {
 
-int rt_comm_unique_id(void *id, size_t bytes) {
-    if (id == nullptr || bytes != sizeof(ncclUniqueId)) return RT_ERR_INVALID;
-    Rccl *api = rccl();
-    if (api == nullptr) return RT_ERR_STATE;
-    ncclUniqueId uid;
-    if (api->getUniqueId(&uid) != ncclSuccess) return RT_ERR_HIP;
-    std::memcpy(id, &uid, sizeof uid);
-    return RT_OK;
-}
+int rt_comm_unique_id(void *id, size_t bytes) { return rtcomm::uniqueId(id, bytes); }
 
 int rt_comm_init(rt_ctx *ctx, int rank, int world, const void *id, size_t bytes) {
-    if (ctx == nullptr || id == nullptr || bytes != sizeof(ncclUniqueId) || world < 1 || rank < 0 || rank >= world) return RT_ERR_INVALID;
-    Rccl *api = rccl();
-    if (api == nullptr) {
-        ctx->hipError = "rt_comm_init: librccl.so.1 could not be loaded";
-        return RT_ERR_STATE;
-    }
+    if (ctx == nullptr || id == nullptr || bytes != rtcomm::kUniqueIdBytes || world < 1 || rank < 0 || rank >= world) return RT_ERR_INVALID;
     RT_HIP(hipSetDevice(ctx->device));
     closeComm(ctx);
-    ncclUniqueId uid;
-    std::memcpy(&uid, id, sizeof uid);
-    ncclComm_t comm = nullptr;
-    RT_NCCL(ctx, api, api->commInitRank(&comm, world, uid, rank));
-    ctx->comm = comm;
+    const int rc = rtcomm::init(&ctx->comm, rank, world, id, bytes, ctx->hipError);
+    if (rc != RT_OK) return rc;
     ctx->commRank = rank;
     ctx->commWorld = world;
     RT_HIP(hipMalloc(reinterpret_cast<void **>(&ctx->dFrameCount), sizeof(unsigned long long)));
@@ -1542,17 +516,14 @@ int rt_reduce(rt_ctx *ctx, int root) {
     if (ctx == nullptr) return RT_ERR_INVALID;
     if (ctx->comm == nullptr || ctx->dAccum == nullptr) return RT_ERR_STATE;
     if (root < 0 || root >= ctx->commWorld) return RT_ERR_INVALID;
-    Rccl *api = rccl();
-    if (api == nullptr) return RT_ERR_STATE;
     RT_HIP(hipSetDevice(ctx->device));
-    ncclComm_t comm = static_cast<ncclComm_t>(ctx->comm);
     const size_t floats = (size_t)ctx->W * ctx->H * 4;
     unsigned long long frames = ctx->framesAccum;
     accumWait(ctx);
     RT_HIP(hipMemcpyAsync(ctx->dFrameCount, &frames, sizeof frames, hipMemcpyHostToDevice, ctx->stream));
     // Both collectives are queued on the context's stream, behind the render work already there.
-    RT_NCCL(ctx, api, api->reduce(ctx->dAccum, ctx->dAccum, floats, ncclFloat, ncclSum, root, comm, ctx->stream));
-    RT_NCCL(ctx, api, api->allReduce(ctx->dFrameCount, ctx->dFrameCount, 1, ncclUint64, ncclSum, comm, ctx->stream));
+    const int rc = rtcomm::reduceSum(ctx->comm, reinterpret_cast<float *>(ctx->dAccum), floats, ctx->dFrameCount, root, ctx->stream, ctx->hipError);
+    if (rc != RT_OK) return rc;
     RT_HIP(hipMemcpyAsync(&frames, ctx->dFrameCount, sizeof frames, hipMemcpyDeviceToHost, ctx->stream));
     if (ctx->commRank != root) RT_HIP(hipMemsetAsync(ctx->dAccum, 0, floats * sizeof(float), ctx->stream));
     RT_HIP(hipStreamSynchronize(ctx->stream));

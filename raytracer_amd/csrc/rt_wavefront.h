@@ -26,7 +26,6 @@ namespace {
 #define RT_WWIDE_ALPHA 6   // alpha-cut four-wide variants WITH analytic primitives: 80 VGPRs with 28 B of spills (the ones without
                            // primitives write hit records through and fit RT_WWIDE waves with 12 B: interior 4K +4 % over 6 waves)
 #endif
-constexpr int kStackDepth = 32;      // int stack[32], src/RayScene.cpp:682
 #ifndef RT_WSTACK
 #define RT_WSTACK 16
 #endif

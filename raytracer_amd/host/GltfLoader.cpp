@@ -33,6 +33,7 @@
 #include <iostream>
 #include <map>
 #include <memory>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -485,6 +486,14 @@ MeshData MeshData::LoadMeshData(std::string modelPath) {
 
     const Json &textures = glb.doc.at("textures");
     mesh.textures.resize(textures.size());
-    for (size_t i = 0; i < textures.size(); ++i) convertTexture(glb, textures.at(i), mesh.textures[i]);
+    for (size_t i = 0; i < textures.size(); ++i) {
+        // An image the machine has no memory for leaves its texture empty, like one that does not decode.
+        try {
+            convertTexture(glb, textures.at(i), mesh.textures[i]);
+        } catch (const std::bad_alloc &) {
+            std::cout << "\tTexture " << i << ": out of memory while decoding; texture left empty" << std::endl;
+            mesh.textures[i] = MeshData::Texture();
+        }
+    }
     return mesh;
 }

@@ -368,6 +368,9 @@ struct Decoder {
         width = (seg[3] << 8) | seg[4];
         // a header may claim 65535 x 65535; textures beyond 16384 x 16384 are refused, not allocated
         if (width > 16384 || height > 16384) return fail("image larger than 16384 x 16384");
+        // Every 8x8 block costs at least one bit of entropy-coded data, so a stream of `size` bytes cannot hold
+        // more than size * 8 * 64 pixels: a short stream with a large header is refused before its planes are allocated.
+        if (static_cast<uint64_t>(width) * static_cast<uint64_t>(height) > static_cast<uint64_t>(size) * 512u) return fail("stream too short for the size the header gives");
         const int n = seg[5];
         if ((n != 1 && n != 3) || segLen < static_cast<size_t>(6 + 3 * n) || width <= 0 || height <= 0)
             return fail("only greyscale and YCbCr images are supported");

@@ -180,6 +180,9 @@ bool DecodePngRGBA(const unsigned char *data, size_t size, int &width, int &heig
         q.offset = total;
         total += (q.rowBytes + 1) * static_cast<size_t>(q.h);
     }
+    // Deflate cannot expand beyond 1032 : 1, so a header that promises more than the data present could
+    // inflate to is refused before anything of that size is allocated (a few header bytes must not cost gigabytes).
+    if (total > (idat.size() + 16) * 1032) { why = "image data too short for the size the header gives"; return false; }
     std::vector<unsigned char> raw(total);
     uLongf rawLen = static_cast<uLongf>(raw.size());
     if (uncompress(raw.data(), &rawLen, idat.data(), static_cast<uLong>(idat.size())) != Z_OK || rawLen != raw.size()) {

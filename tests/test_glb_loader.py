@@ -533,3 +533,30 @@ def test_jpeg_header_claiming_a_huge_image_leaves_the_texture_empty(tmp_path):
     sc = load(g.write(tmp_path / "huge.glb"))
     assert sc.model_stats(0)["triangles"] == 2
     assert sc.streams[5].size < 64                                           # header words at most, no texels
+
+
+def test_headers_within_the_size_limit_but_without_the_data_allocate_nothing(tmp_path):
+    """A few header bytes claiming 16384 x 16384 (inside the readers' size limit) must not cost gigabytes:
+    deflate expands at most 1032 : 1 and a JPEG block needs at least one bit, so both readers refuse a
+    stream too short for its header before sizing any buffer from it."""
+    import resource
+    import struct
+    import zlib
+
+    def chunk(kind, body):
+        return struct.pack(">I", len(body)) + kind + body + struct.pack(">I", zlib.crc32(kind + body) & 0xffffffff)
+    png = (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", 16384, 16384, 16, 6, 0, 0, 0)) +
+           chunk(b"IDAT", zlib.compress(b"\0" * 64)) + chunk(b"IEND", b""))
+    sof = b"\xff\xc2" + struct.pack(">HBHHB", 17, 8, 16384, 16384, 3) + bytes([1, 0x22, 0, 2, 0x11, 0, 3, 0x11, 0])
+    jpeg = b"\xff\xd8" + sof + b"\xff\xd9"
+    before = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+    for name, stream in (("png", png), ("jpeg", jpeg)):
+        pos, idx = _two_triangles()
+        g = GlbBuilder()
+        mat = g.material(pbrMetallicRoughness={"baseColorTexture": {"index": g.texture(stream)}})
+        g.node(mesh=g.mesh([g.primitive(pos, idx, material=mat, uvs=pos[:, :2])]), root=True)
+        sc = load(g.write(tmp_path / f"claim_{name}.glb"))
+        assert sc.model_stats(0)["triangles"] == 2
+        assert sc.streams[5].size < 64
+    grown_kib = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss - before
+    assert grown_kib < 256 * 1024, f"peak resident size grew by {grown_kib >> 10} MiB"
