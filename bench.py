@@ -90,6 +90,7 @@ def launch_ranks(args):
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     rc = 0
     pending = list(procs)
+    give_up_at = None
     while pending:
         for p in list(pending):
             code = p.poll()
@@ -98,8 +99,13 @@ def launch_ranks(args):
             pending.remove(p)
             if code != 0 and rc == 0:
                 rc = code if code > 0 else 128 - code
-                for q in pending:   # a rank that died leaves the others waiting in a collective
-                    q.terminate()
+                # A rank that died leaves the others waiting in a collective: they get a few seconds to end by
+                # themselves (and say why), then they are ended.
+                give_up_at = time.time() + 5.0
+        if give_up_at is not None and time.time() > give_up_at:
+            for q in pending:
+                q.terminate()
+            give_up_at = time.time() + 3600.0
         time.sleep(0.05)
     return rc
 
