@@ -22,6 +22,9 @@ HOST_HDRS := $(wildcard $(HOST)/*.h $(HOST)/gpu/*.h $(HOST)/glm/*.hpp $(HOST)/gl
 
 all: $(LIBDIR)/librt_hip.so $(LIBDIR)/librt_host.so oracle/liboracle.so examples/rt_render
 
+# Identity of the library's code: a hash over its sources and flags (rt_build_id()); profiles carry it.
+BUILD_ID := $(shell cat $(CSRC)/*.h $(CSRC)/*.hip $(CSRC)/*.cpp include/rt_hip.h | sha1sum | cut -c1-12)
+
 # The device assembly is kept (build/*.s) and audited before the library is installed: hand-written
 # instructions next to a transcendental result they read (a hazard the compiler does not see inside asm
 # blocks), and spill bytes of every kernel against the audited figures of tools/spill_budget.json.
@@ -39,7 +42,7 @@ $(BUILD)/rt_comm.o: $(CSRC)/rt_comm.cpp $(CSRC)/rt_comm.h include/rt_hip.h
 
 $(LIBDIR)/librt_hip.so: $(CSRC)/rt_hip.hip $(wildcard $(CSRC)/*.h) include/rt_hip.h $(BUILD)/rt_commit.o $(BUILD)/rt_comm.o tools/isa_audit.py tools/spill_budget.json
 	@mkdir -p $(LIBDIR) $(BUILD)
-	cd $(BUILD) && $(HIPCC) $(subst -Iinclude,-I$(CURDIR)/include,$(subst -I$(CSRC),-I$(CURDIR)/$(CSRC),$(HIPFLAGS))) $(EXTRA_HIPFLAGS) -save-temps -c $(CURDIR)/$(CSRC)/rt_hip.hip -o rt_hip.o
+	cd $(BUILD) && $(HIPCC) $(subst -Iinclude,-I$(CURDIR)/include,$(subst -I$(CSRC),-I$(CURDIR)/$(CSRC),$(HIPFLAGS))) $(EXTRA_HIPFLAGS) -DRT_BUILD_ID='"$(BUILD_ID)"' -save-temps -c $(CURDIR)/$(CSRC)/rt_hip.hip -o rt_hip.o
 	$(HIPCC) --offload-arch=$(ARCH) -fPIC -pthread -shared $(BUILD)/rt_hip.o $(BUILD)/rt_commit.o $(BUILD)/rt_comm.o -o $(BUILD)/librt_hip.so
 	python3 tools/isa_audit.py $(DEVICE_ASM) --budget tools/spill_budget.json
 	cp $(BUILD)/librt_hip.so $@

@@ -287,11 +287,33 @@ int rt_set_counters(rt_ctx *ctx, int enabled);
  *                            again after changing it.
  *   RT_OPT_PIPELINE          1 (default): small render calls overlap on the device, see rt_render.
  *                            0: every call runs on the context's one stream, after the call before
- *                            it (also: environment variable RT_PIPELINE=0).  Same output either way. */
+ *                            it (also: environment variable RT_PIPELINE=0).  Same output either way.
+ *   RT_OPT_TEXTURE_U8        1 (default): a four-channel texture whose uploaded words all equal (float)k / 255.0f
+ *                            for k = 0..255 -- what the reference's loader makes of an 8-bit image,
+ *                            src/MeshData.cpp:556-587 -- is kept on the device as one RGBA8 word per texel, a
+ *                            quarter of the bytes; fetches (src/RayScene.cpp:337-380) return the same floats, bit for
+ *                            bit, through a 256-entry table.  Textures no material refers to are not copied at
+ *                            all.  0 keeps the uploaded words.  Re-commits a committed scene.  Env RT_TEX_U8.
+ */
 enum { RT_OPT_SHADOW_EARLY_OUT = 1, RT_OPT_REFILL_LANES = 2, RT_OPT_INNER_SHARE = 3, RT_OPT_MAX_PATHS = 4, RT_OPT_TILE_MAJOR = 5,
        RT_OPT_SPECTRAL_PDF_AS_WRITTEN = 6, RT_OPT_WIDE_BVH = 7, RT_OPT_HERO_WAVELENGTH = 8, RT_OPT_NEE = 9,
-       RT_OPT_STRATIFIED = 10, RT_OPT_PIPELINE = 11 };
+       RT_OPT_STRATIFIED = 10, RT_OPT_PIPELINE = 11, RT_OPT_TEXTURE_U8 = 12 };
 int rt_set_option(rt_ctx *ctx, int option, int value);
+
+/* Facts about the committed scene as the device holds it (no reference counterpart: the reference's
+ * TBO upload, src/glUtilities/TextureBuffer.cpp:23-38, reports nothing).
+ *   RT_INFO_TEXTURE_BYTES_UPLOADED  bytes of the texture stream given to rt_upload
+ *   RT_INFO_TEXTURE_BYTES_DEVICE    bytes of the texture buffer the kernels read (RT_OPT_TEXTURE_U8)
+ *   RT_INFO_TEXTURES_RGBA8 / _FP32  textures in use kept as RGBA8 words / as fp32 words
+ *   RT_INFO_TREE_MODE               RT_OPT_WIDE_BVH value in effect for this scene (0 when the default was declined for it) */
+enum { RT_INFO_TEXTURE_BYTES_UPLOADED = 1, RT_INFO_TEXTURE_BYTES_DEVICE = 2, RT_INFO_TEXTURES_RGBA8 = 3, RT_INFO_TEXTURES_FP32 = 4,
+       RT_INFO_TREE_MODE = 5 };
+int rt_get_info(rt_ctx *ctx, int what, uint64_t *value);
+
+/* Identifies the build of the library: a hash over its kernel and host sources and compiler flags,
+ * made by the Makefile.  Profiles record it, so that a measurement can be told from one taken on
+ * other code (no reference counterpart). */
+const char *rt_build_id(void);
 
 const char *rt_strerror(int status);
 const char *rt_last_hip_error(rt_ctx *ctx);

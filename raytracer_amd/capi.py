@@ -21,13 +21,15 @@ RT_OPT_HERO_WAVELENGTH = 8
 RT_OPT_NEE = 9
 RT_OPT_STRATIFIED = 10
 RT_OPT_PIPELINE = 11
+RT_OPT_TEXTURE_U8 = 12
+RT_INFO_TEXTURE_BYTES_UPLOADED, RT_INFO_TEXTURE_BYTES_DEVICE, RT_INFO_TEXTURES_RGBA8, RT_INFO_TEXTURES_FP32, RT_INFO_TREE_MODE = 1, 2, 3, 4, 5
 
 # Every symbol include/rt_hip.h declares.
 HIP_SYMBOLS = [
     "rt_create", "rt_destroy", "rt_upload", "rt_commit_scene", "rt_resize", "rt_set_frame", "rt_render", "rt_reserve",
     "rt_reset_accum", "rt_sync", "rt_readback", "rt_display_rgba8", "rt_display_rgba8_noalloc", "rt_display_rgba8_begin", "rt_display_rgba8_end", "rt_restore_accum", "rt_accum_device_ptr", "rt_bind_accum", "rt_add_frames",
     "rt_trace_primary", "rt_eval_colour", "rt_get_stats", "rt_reset_stats", "rt_set_counters", "rt_set_option", "rt_set_tile_shard", "rt_strerror", "rt_last_hip_error",
-    "rt_comm_unique_id", "rt_comm_init", "rt_reduce",
+    "rt_comm_unique_id", "rt_comm_init", "rt_reduce", "rt_get_info", "rt_build_id",
 ]
 # Every symbol include/rt_host.h declares.
 HOST_SYMBOLS = [
@@ -35,6 +37,11 @@ HOST_SYMBOLS = [
     "rth_scene_model_stats", "rth_camera_make", "rth_engine_create", "rth_engine_render", "rth_engine_frame",
     "rth_engine_free", "rth_write_png", "rth_write_pfm",
 ]
+
+
+def build_id():
+    """Hash of the sources and flags librt_hip.so was built from."""
+    return hip.rt_build_id().decode()
 
 
 class RtCamera(C.Structure):
@@ -117,6 +124,9 @@ hip.rt_set_tile_shard.argtypes = [_vp, _u32, _u32]
 hip.rt_comm_unique_id.argtypes = [_vp, _sz]
 hip.rt_comm_init.argtypes = [_vp, _i, _i, _vp, _sz]
 hip.rt_reduce.argtypes = [_vp, _i]
+hip.rt_get_info.argtypes = [_vp, _i, C.POINTER(C.c_uint64)]
+hip.rt_build_id.argtypes = []
+hip.rt_build_id.restype = C.c_char_p
 hip.rt_strerror.argtypes = [_i]
 hip.rt_strerror.restype = C.c_char_p
 hip.rt_last_hip_error.argtypes = [_vp]
@@ -340,6 +350,11 @@ class Backend:
 
     def set_option(self, option, value):
         self._check(hip.rt_set_option(self._ctx, option, int(value)))
+
+    def info(self, what):
+        value = C.c_uint64(0)
+        self._check(hip.rt_get_info(self._ctx, what, C.byref(value)))
+        return int(value.value)
 
     def set_counters(self, enabled):
         self._check(hip.rt_set_counters(self._ctx, 1 if enabled else 0))

@@ -229,6 +229,97 @@ int repackScene(rt_scene_host *ctx, std::vector<PackedNode> &nodes, std::vector<
     return RT_OK;
 }
 
+void colourTables8(float table[512]) {
+    for (int k = 0; k < 256; ++k) {
+        table[k] = (float)k / 255.0f;
+        table[256 + k] = srgbToLinear(table[k]);
+    }
+}
+
+void packTextures(const rt_scene_host *ctx, bool enable, TexturePack &out) {
+    const std::vector<float> &mats = ctx->host[RT_SLOT_MATERIALS];
+    const std::vector<float> &tex = ctx->host[RT_SLOT_TEXTURES];
+    out.words.clear();
+    out.materials = mats;
+    out.packed8 = out.kept32 = 0;
+    out.sourceBytes = tex.size() * sizeof(float);
+    auto keepUpload = [&]() {
+        out.words = tex;
+        out.materials = mats;
+        out.packed8 = out.kept32 = 0;
+    };
+    if (!enable) { keepUpload(); return; }
+    float unorm[512];
+    colourTables8(unorm);
+    uint32_t unormBits[256];
+    for (int k = 0; k < 256; ++k) std::memcpy(&unormBits[k], &unorm[k], 4);
+
+    // Textures in use, by the word offset of their header (repackScene has validated every reference).
+    const int materialCount = (int)(mats.size() / kMaterialWords);
+    std::vector<int32_t> refs;
+    for (int m = 0; m < materialCount; ++m)
+        for (int k = 0; k < 6; ++k) {
+            const int32_t ref = f2i(mats[(size_t)m * kMaterialWords + k]);
+            if (ref != -1) refs.push_back(ref);
+        }
+    std::sort(refs.begin(), refs.end());
+    refs.erase(std::unique(refs.begin(), refs.end()), refs.end());
+    // References that overlap each other (a stream nobody's loader writes) could multiply the data: such a
+    // scene keeps the upload as it is.
+    const size_t budget = 2 * tex.size() + 64 * refs.size() + 64;
+    std::vector<int32_t> movedTo(refs.size(), -1);
+    for (size_t i = 0; i < refs.size(); ++i) {
+        const size_t ref = (size_t)refs[i];
+        const int w = f2i(tex[ref]), h = f2i(tex[ref + 1]), c = f2i(tex[ref + 2]);
+        const size_t texels = (size_t)w * (size_t)h, count = texels * (size_t)c;
+        const float *src = &tex[ref + 5];
+        bool eightBit = c == 4 || c == 3;
+        // (every word must be one of the 256 values exactly: the kernels return table[k])
+        std::vector<uint32_t> packed;
+        if (eightBit) {
+            packed.resize(texels);
+            for (size_t t = 0; t < texels && eightBit; ++t) {
+                uint32_t word = 0;
+                // a three-channel texel carries the red of the texel after it in its fourth byte: the word the
+                // reference's alpha fetch reads there (what follows the LAST texel is kept as a raw word instead)
+                const int take = (c == 3 && t + 1 == texels) ? 3 : 4;
+                for (int ch = 0; ch < take; ++ch) {
+                    const float f = src[t * (size_t)c + (size_t)ch];
+                    uint32_t bits;
+                    std::memcpy(&bits, &f, 4);
+                    const int k = (f >= 0.0f && f <= 1.0f) ? (int)(f * 255.0f + 0.5f) : -1;
+                    if (k < 0 || k > 255 || unormBits[k] != bits) { eightBit = false; break; }
+                    word |= (uint32_t)k << (8 * ch);
+                }
+                packed[t] = word;
+            }
+        }
+        if (out.words.size() + 5 + (eightBit ? texels + 1 : count + 3) > budget) { keepUpload(); return; }
+        movedTo[i] = (int32_t)out.words.size();
+        for (int k = 0; k < 5; ++k) out.words.push_back(tex[ref + (size_t)k]);
+        if (eightBit) {
+            const int32_t marked = c | (int32_t)kTexPacked8;
+            std::memcpy(&out.words[out.words.size() - 3], &marked, 4);
+            const size_t at = out.words.size();
+            out.words.resize(at + texels);
+            std::memcpy(&out.words[at], packed.data(), texels * 4);
+            out.words.push_back(ref + 5 + count < tex.size() ? tex[ref + 5 + count] : 0.0f);   // the word behind the last texel, as uploaded
+            ++out.packed8;
+        } else {
+            out.words.insert(out.words.end(), src, src + count);
+            for (size_t k = 0; k < 3; ++k) out.words.push_back(ref + 5 + count + k < tex.size() ? tex[ref + 5 + count + k] : 0.0f);
+            ++out.kept32;
+        }
+    }
+    for (int m = 0; m < materialCount; ++m)
+        for (int k = 0; k < 6; ++k) {
+            const int32_t ref = f2i(mats[(size_t)m * kMaterialWords + k]);
+            if (ref == -1) continue;
+            const size_t i = (size_t)(std::lower_bound(refs.begin(), refs.end(), ref) - refs.begin());
+            std::memcpy(&out.materials[(size_t)m * kMaterialWords + k], &movedTo[i], 4);
+        }
+}
+
 // RT_COMMIT_TIMING=1: prints the host time since `since` under the name `what`, and restarts the clock.
 void commitLap(const char *what, std::chrono::steady_clock::time_point &since) {
     static const bool on = std::getenv("RT_COMMIT_TIMING") != nullptr;

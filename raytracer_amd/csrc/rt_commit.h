@@ -23,6 +23,30 @@ struct rt_scene_host {
 
 namespace rtc {
 
+// What packTextures did, for rt_get_info.
+struct TexturePack {
+    std::vector<float> words;        // the texture buffer the kernels read (headers + texels, see packTextures)
+    std::vector<float> materials;    // the materials stream with its texture references pointing into `words`
+    uint64_t packed8 = 0, kept32 = 0;       // textures stored as RGBA8 words / as fp32 words
+    uint64_t sourceBytes = 0;               // bytes of the uploaded texture stream
+};
+
+// Device copy of the textures (the reference's loader turns 8-bit images into one fp32 word per channel, four
+// times their size, src/MeshData.cpp:556-606).  Every texture a material refers to is copied into `out.words`;
+// a three- or four-channel texture whose texels all equal (float)k / 255.0f bit for bit, k = 0..255, is stored
+// as one 32-bit word per texel holding the k of its channels (channel c in byte c) and marked kTexPacked8 in
+// its header's channel word; the kernels turn k back into the same float through a 256-entry table of
+// k / 255.0f.  The reference's alpha fetch reads a fourth word whatever the channel count
+// (src/RayScene.cpp:571-572): a three-channel texel keeps the next texel's red in its fourth byte, and the word
+// that followed the last texel in the upload is kept as it was behind the packed texels.  Other textures
+// keep their fp32 words, followed by the three words that followed them in the upload.  `enable` false copies
+// the uploaded stream and materials unchanged.
+void packTextures(const rt_scene_host *ctx, bool enable, TexturePack &out);
+
+// table[k] = (float)k / 255.0f and table[256 + k] = srgb_to_linear of it (src/RayScene.cpp:268-277), computed
+// with the same pinned arithmetic the kernels would run per fetch.
+void colourTables8(float table[512]);
+
 // Builds the traversal re-pack from the uploaded model streams and validates every offset the
 // kernels will follow.  RT_ERR_SCENE for a stream the kernels could not walk safely.
 int repackScene(rt_scene_host *ctx, std::vector<rtd::PackedNode> &nodes, std::vector<rtd::PackedTri> &tris, std::vector<rtd::PackedShade> &shade,

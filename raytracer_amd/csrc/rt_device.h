@@ -130,8 +130,10 @@ struct SceneView {
     const PackedTri *wtris;     // four-wide trees: the triangles in THEIR leaf order; `ident` holds the index into tris
     const TriPair *wpairs;      // four-wide trees of scenes without alpha-cut textures: the leaves as triangle pairs (leaf references then count pairs)
     const ModelDesc *modelDesc;
+    const float *unorm8;        // [512]: k / 255.0f for k = 0..255, then srgb_to_linear of each (textures stored as RGBA8)
     int32_t objectCount, modelsCount, lightSourcesCount;
 };
+constexpr int32_t kTexPacked8 = 1 << 16;   // in a texture header's channel word: texels are RGBA8 words
 
 // Hit record written by the traversal kernel: 16 bytes.
 //   id == kMiss            : nothing hit (t = 1e20)
@@ -226,12 +228,41 @@ RT_FN float wrapCoord(int mode, float x) {
     }
     return x;
 }
-RT_FN int texelOffset(const SceneView &sc, int header, V2 uv) {
+// A texel of the device's texture buffer.  `at` is the word offset of its first channel, or, for a texture the
+// commit stored with 8-bit channels (kTexPacked8 in the header's channel word), of the one word that holds
+// them.  Channel k of the texel, and the words after it that the reference's fetches reach
+// (src/RayScene.cpp:571-572 reads a fourth word whatever the channel count), come back from texelWord.
+struct TexelAt {
+    int at;
+    uint32_t packed;      // 8-bit texels: channel c in byte c; a three-channel texel holds the next texel's red in byte 3
+    int tail;             // 8-bit three-channel textures, last texel only: word offset of the raw word behind the texture; else 0
+    bool is8;
+};
+RT_FN TexelAt texelAt(const SceneView &sc, int header, V2 uv) {
     const float *h = sc.textures + header;
     int width = f2i(h[0]), height = f2i(h[1]), channels = f2i(h[2]), wrapS = f2i(h[3]), wrapT = f2i(h[4]);
     float x = clamp_(wrapCoord(wrapS, uv.x), 0.0f, 0.999999f);
     float y = clamp_(wrapCoord(wrapT, uv.y), 0.0f, 0.999999f);
-    return header + 5 + ((int)(x * (float)width) + (int)(y * (float)height) * width) * channels;
+    const int texel = (int)(x * (float)width) + (int)(y * (float)height) * width;
+    TexelAt t;
+    t.is8 = (channels & kTexPacked8) != 0;
+    t.at = header + 5 + (t.is8 ? texel : texel * channels);
+    t.packed = t.is8 ? f2u(sc.textures[t.at]) : 0u;
+    t.tail = (channels == (3 | kTexPacked8) && texel == width * height - 1) ? header + 5 + width * height : 0;
+    return t;
+}
+// Channel k (0..3) as the float the upload held: (float)byte / 255.0f through the table for 8-bit texels.
+RT_FN float texelWord(const SceneView &sc, const TexelAt &t, int k) {
+    if (t.is8) {
+        if (k == 3 && t.tail != 0) return sc.textures[t.tail];
+        return sc.unorm8[(t.packed >> (8 * k)) & 0xffu];
+    }
+    return sc.textures[t.at + k];
+}
+// srgb_to_linear of channel k; RGBA8 texels take it from the table made with the same arithmetic at commit.
+RT_FN float texelLinear(const SceneView &sc, const TexelAt &t, int k) {
+    if (t.is8) return sc.unorm8[256u + ((t.packed >> (8 * k)) & 0xffu)];
+    return srgbToLinear(sc.textures[t.at + k]);
 }
 
 // Barycentric UV interpolation used for texturing (Cramer form, src/RayScene.cpp:764-780).
@@ -272,14 +303,14 @@ RT_FN void applyTextures(const SceneView &sc, HitInfoD &info, V3 rd, V3 vertexA,
     V2 uv = cramerUV(vertexA, edgeAB, edgeAC, uv0, uv1, uv2, info.point);
     MaterialD &m = info.mat;
     if (m.baseColorTexture != -1) {
-        int at = texelOffset(sc, m.baseColorTexture, uv);
-        m.albedo = v3(srgbToLinear(sc.textures[at]), srgbToLinear(sc.textures[at + 1]), srgbToLinear(sc.textures[at + 2]));
-        m.transmission *= 1.0f - sc.textures[at + 3];
+        const TexelAt t = texelAt(sc, m.baseColorTexture, uv);
+        m.albedo = v3(texelLinear(sc, t, 0), texelLinear(sc, t, 1), texelLinear(sc, t, 2));
+        m.transmission *= 1.0f - texelWord(sc, t, 3);
     }
     if (m.metallicRoughnessTexture != -1) {
-        int at = texelOffset(sc, m.metallicRoughnessTexture, uv);
-        m.roughness *= sc.textures[at + 1];
-        m.metallic *= sc.textures[at + 2];
+        const TexelAt t = texelAt(sc, m.metallicRoughnessTexture, uv);
+        m.roughness *= texelWord(sc, t, 1);
+        m.metallic *= texelWord(sc, t, 2);
     }
     if (m.normalTexture != -1) {
         // Tangent frame from the triangle's UVs (src/RayScene.cpp:597-621); the
@@ -294,8 +325,8 @@ RT_FN void applyTextures(const SceneView &sc, HitInfoD &info, V3 rd, V3 vertexA,
             if (length(tangent) > kMinDenominator) {
                 tangent = normalize(tangent);
                 V3 bitangent = cross(info.normal, tangent);
-                int at = texelOffset(sc, m.normalTexture, uv);
-                V3 tn = ld3(sc.textures, at) * 2.0f - v3s(1.0f);
+                const TexelAt t = texelAt(sc, m.normalTexture, uv);
+                V3 tn = v3(texelWord(sc, t, 0), texelWord(sc, t, 1), texelWord(sc, t, 2)) * 2.0f - v3s(1.0f);
                 tn.x *= m.normalScale;
                 tn.y *= m.normalScale;
                 tn = normalize(tn);
@@ -305,16 +336,16 @@ RT_FN void applyTextures(const SceneView &sc, HitInfoD &info, V3 rd, V3 vertexA,
         }
     }
     if (m.emissiveTexture != -1) {
-        int at = texelOffset(sc, m.emissiveTexture, uv);
-        m.emissionColor = m.emissionColor * ld3(sc.textures, at);
+        const TexelAt t = texelAt(sc, m.emissiveTexture, uv);
+        m.emissionColor = m.emissionColor * v3(texelWord(sc, t, 0), texelWord(sc, t, 1), texelWord(sc, t, 2));
     }
     if (m.transmissionTexture != -1) {
-        int at = texelOffset(sc, m.transmissionTexture, uv);
-        m.transmission *= sc.textures[at];
+        const TexelAt t = texelAt(sc, m.transmissionTexture, uv);
+        m.transmission *= texelWord(sc, t, 0);
     }
     if (m.occlusionTexture != -1) {
-        int at = texelOffset(sc, m.occlusionTexture, uv);
-        m.transmission *= 1.0f - (1.0f - sc.textures[at]) * (1.0f - m.occlusionStrength);
+        const TexelAt t = texelAt(sc, m.occlusionTexture, uv);
+        m.transmission *= 1.0f - (1.0f - texelWord(sc, t, 0)) * (1.0f - m.occlusionStrength);
     }
 }
 

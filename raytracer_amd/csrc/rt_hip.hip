@@ -116,6 +116,9 @@ struct rt_ctx : rt_scene_host {
     bool nee = true;
     bool stratified = true;
     uint32_t tileOffset = 0, tileStride = 1;
+    bool textureU8 = true;     // RT_OPT_TEXTURE_U8 / env RT_TEX_U8: 8-bit textures are kept as RGBA8 words on the device
+    float *dUnorm8 = nullptr;  // [512] k / 255.0f and srgb_to_linear of it (rt_create)
+    uint64_t texturesPacked8 = 0, texturesKept32 = 0, textureBytesUploaded = 0, textureBytesDevice = 0;
     bool planesInner = true;   // tile-major path order inside a batch
     int refillLanes = 32;   // idle lanes that trigger a refill for stages > 0
     bool refillChosen = false;   // set through the option or the environment
@@ -561,6 +564,19 @@ int rt_create(rt_ctx **out, int device) {
         long v = std::atol(env);
         if (v > 0) ctx->maxPaths = (uint32_t)std::min<long>(v, 1l << 30);
     }
+    // The 8-bit colour tables of textures kept as RGBA8 (512 floats).
+    {
+        float table[512];
+        colourTables8(table);
+        if (hipMalloc(reinterpret_cast<void **>(&ctx->dUnorm8), sizeof table) != hipSuccess ||
+            hipMemcpy(ctx->dUnorm8, table, sizeof table, hipMemcpyHostToDevice) != hipSuccess) {
+            if (ctx->dUnorm8) hipFree(ctx->dUnorm8);
+            hipStreamDestroy(ctx->stream);
+            delete ctx;
+            return RT_ERR_HIP;
+        }
+    }
+    if (const char *env = std::getenv("RT_TEX_U8")) ctx->textureU8 = std::atoi(env) != 0;
     if (const char *env = std::getenv("RT_TILE_MAJOR")) ctx->planesInner = std::atoi(env) != 0;
     if (const char *env = std::getenv("RT_PIPELINE")) ctx->pipelineOn = std::atoi(env) != 0;
     if (const char *env = std::getenv("RT_WIDE_BVH")) {
@@ -597,7 +613,7 @@ void rt_destroy(rt_ctx *ctx) {
         if (d.copied) hipEventDestroy(d.copied);
     }
     for (float *p : ctx->dStream) if (p) hipFree(p);
-    void *owned[] = {ctx->dNodes, ctx->dWNodes, ctx->dW8Nodes, ctx->dWPairs, ctx->pb.overflow, ctx->pb.retrace, ctx->dWTris, ctx->dTris, ctx->dShade, ctx->dUVs, ctx->dLightTris, ctx->dPrimAt, ctx->dModelDesc, ctx->accumExternal ? nullptr : (void *)ctx->dAccum, ctx->dPartial,
+    void *owned[] = {ctx->dNodes, ctx->dWNodes, ctx->dW8Nodes, ctx->dWPairs, ctx->pb.overflow, ctx->pb.retrace, ctx->dWTris, ctx->dTris, ctx->dShade, ctx->dUVs, ctx->dLightTris, ctx->dPrimAt, ctx->dModelDesc, ctx->dUnorm8, ctx->accumExternal ? nullptr : (void *)ctx->dAccum, ctx->dPartial,
                      ctx->pb.rays, ctx->pb.hits, ctx->pb.stA, ctx->pb.stB, ctx->pb.neeA, ctx->pb.neeB, ctx->pb.neeC,
                      ctx->pb.qExt[0], ctx->pb.qExt[1], ctx->pb.qShadow, ctx->pb.stages, ctx->pb.counters, ctx->pb.cameraHits};
     for (void *p : owned) if (p) hipFree(p);
@@ -654,14 +670,24 @@ static int commitScene(rt_ctx *ctx, int objectCount, int modelsCount, int lightS
     if (rc != RT_OK) return rc;
     lap("validate + re-pack", mark);
 
+    // The textures the materials use, 8-bit ones as RGBA8 words (a quarter of the upload's bytes), and the
+    // materials with their references moved along.
+    TexturePack texturePack;
+    packTextures(ctx, ctx->textureU8, texturePack);
+    ctx->texturesPacked8 = texturePack.packed8;
+    ctx->texturesKept32 = texturePack.kept32;
+    ctx->textureBytesUploaded = texturePack.sourceBytes;
+    ctx->textureBytesDevice = texturePack.words.size() * sizeof(float);
+    lap("texture re-pack", mark);
     // Raw streams, each padded with 8 zero words so the one-past-the-end reads the
     // reference's texel fetches can make (4th channel of the last RGB texel) stay in bounds.
     for (int s = 1; s <= 5; ++s) {
-        std::vector<float> padded(ctx->host[s]);
-        padded.resize(padded.size() + 8, 0.0f);
-        if ((rc = devAlloc(ctx, &ctx->dStream[s], padded.size())) != RT_OK) return rc;
-        RT_HIP(hipMemcpy(ctx->dStream[s], padded.data(), padded.size() * sizeof(float), hipMemcpyHostToDevice));
-        ctx->dStreamWords[s] = ctx->host[s].size();
+        std::vector<float> &src = s == RT_SLOT_TEXTURES ? texturePack.words : s == RT_SLOT_MATERIALS ? texturePack.materials : ctx->host[s];
+        const size_t words = src.size();
+        if ((rc = devAlloc(ctx, &ctx->dStream[s], words + 8)) != RT_OK) return rc;
+        if (words != 0) RT_HIP(hipMemcpy(ctx->dStream[s], src.data(), words * sizeof(float), hipMemcpyHostToDevice));
+        RT_HIP(hipMemset(ctx->dStream[s] + words, 0, 8 * sizeof(float)));
+        ctx->dStreamWords[s] = words;
     }
     lap("stream upload", mark);
     std::vector<WideNode> wnodes;
@@ -740,6 +766,7 @@ static int commitScene(rt_ctx *ctx, int objectCount, int modelsCount, int lightS
     v.lightTris = ctx->dLightTris;
     v.primAt = ctx->dPrimAt;
     v.modelDesc = ctx->dModelDesc;
+    v.unorm8 = ctx->dUnorm8;
     v.objectCount = objectCount;
     v.modelsCount = modelsCount;
     v.lightSourcesCount = lightSourcesCount;
@@ -1247,6 +1274,12 @@ int rt_set_option(rt_ctx *ctx, int option, int value) {
         case RT_OPT_PIPELINE:
             ctx->pipelineOn = value != 0;
             return RT_OK;
+        case RT_OPT_TEXTURE_U8:
+            if (ctx->textureU8 == (value != 0)) return RT_OK;
+            ctx->textureU8 = value != 0;
+            if (!ctx->committed) return RT_OK;
+            ctx->dirty = true;   // the device copy of the textures belongs to the committed scene
+            return rt_commit_scene(ctx, ctx->objectCount, ctx->modelsCount, ctx->lightSourcesCount);
         case RT_OPT_WIDE_BVH:
             if (value < 0 || value > 4) return RT_ERR_INVALID;
             ctx->wideChosen = true;
@@ -1259,6 +1292,23 @@ int rt_set_option(rt_ctx *ctx, int option, int value) {
             return RT_ERR_INVALID;
     }
 }
+
+int rt_get_info(rt_ctx *ctx, int what, uint64_t *value) {
+    if (ctx == nullptr || value == nullptr) return RT_ERR_INVALID;
+    switch (what) {
+        case RT_INFO_TEXTURE_BYTES_UPLOADED: *value = ctx->textureBytesUploaded; return RT_OK;
+        case RT_INFO_TEXTURE_BYTES_DEVICE: *value = ctx->textureBytesDevice; return RT_OK;
+        case RT_INFO_TEXTURES_RGBA8: *value = ctx->texturesPacked8; return RT_OK;
+        case RT_INFO_TEXTURES_FP32: *value = ctx->texturesKept32; return RT_OK;
+        case RT_INFO_TREE_MODE: *value = (uint64_t)ctx->wideNow; return RT_OK;
+        default: return RT_ERR_INVALID;
+    }
+}
+
+#ifndef RT_BUILD_ID
+#define RT_BUILD_ID "unversioned"
+#endif
+const char *rt_build_id(void) { return RT_BUILD_ID; }
 
 int rt_set_counters(rt_ctx *ctx, int enabled) {
     if (ctx == nullptr) return RT_ERR_INVALID;

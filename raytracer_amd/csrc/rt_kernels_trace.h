@@ -67,8 +67,8 @@ __device__ __forceinline__ bool alphaCutRejects(const SceneView &sc, uint32_t tr
     float alphaCut = m[20];
     V2 uv = cramerUV(v3(pt.a[0], pt.a[1], pt.a[2]), v3(pt.ab[0], pt.ab[1], pt.ab[2]), v3(pt.ac[0], pt.ac[1], pt.ac[2]),
                      v2(ps.uv0[0], ps.uv0[1]), v2(ps.uv1[0], ps.uv1[1]), v2(ps.uv2[0], ps.uv2[1]), ro + t * rd);
-    int at = texelOffset(sc, baseColor, uv);
-    return sc.textures[at + 3] < alphaCut;
+    const TexelAt tx = texelAt(sc, baseColor, uv);
+    return texelWord(sc, tx, 3) < alphaCut;
 }
 
 // Pins loaded values at this point of the program, so that the compiler cannot sink one of the
