@@ -40,10 +40,20 @@ $(BUILD)/rt_comm.o: $(CSRC)/rt_comm.cpp $(CSRC)/rt_comm.h include/rt_hip.h
 	@mkdir -p $(BUILD)
 	$(CXX) $(COMMIT_FLAGS) -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -c $< -o $@
 
-$(LIBDIR)/librt_hip.so: $(CSRC)/rt_hip.hip $(wildcard $(CSRC)/*.h) include/rt_hip.h $(BUILD)/rt_commit.o $(BUILD)/rt_comm.o tools/isa_audit.py tools/spill_budget.json
+# The opt-in fast-arithmetic build of the shading kernels (RT_OPT_FAST_SHADE): same sources, the hardware's
+# reciprocal / square root / transcendental instructions, contraction allowed.
+FASTFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=fast -fno-hip-fp32-correctly-rounded-divide-sqrt -freciprocal-math \
+             -pthread -Wall -Wno-unused-function -Wno-unused-result -Wno-unused-value -I$(CURDIR)/include -I$(CURDIR)/$(CSRC)
+FAST_ASM := $(BUILD)/rt_shade_fast-hip-amdgcn-amd-amdhsa-$(ARCH).s
+$(BUILD)/rt_shade_fast.o: $(CSRC)/rt_shade_fast.hip $(wildcard $(CSRC)/*.h)
+	@mkdir -p $(BUILD)
+	cd $(BUILD) && $(HIPCC) $(FASTFLAGS) -save-temps -c $(CURDIR)/$(CSRC)/rt_shade_fast.hip -o rt_shade_fast.o
+	python3 tools/isa_audit.py $(FAST_ASM)
+
+$(LIBDIR)/librt_hip.so: $(BUILD)/rt_shade_fast.o $(CSRC)/rt_hip.hip $(wildcard $(CSRC)/*.h) include/rt_hip.h $(BUILD)/rt_commit.o $(BUILD)/rt_comm.o tools/isa_audit.py tools/spill_budget.json
 	@mkdir -p $(LIBDIR) $(BUILD)
 	cd $(BUILD) && $(HIPCC) $(subst -Iinclude,-I$(CURDIR)/include,$(subst -I$(CSRC),-I$(CURDIR)/$(CSRC),$(HIPFLAGS))) $(EXTRA_HIPFLAGS) -DRT_BUILD_ID='"$(BUILD_ID)"' -save-temps -c $(CURDIR)/$(CSRC)/rt_hip.hip -o rt_hip.o
-	$(HIPCC) --offload-arch=$(ARCH) -fPIC -pthread -shared $(BUILD)/rt_hip.o $(BUILD)/rt_commit.o $(BUILD)/rt_comm.o -o $(BUILD)/librt_hip.so
+	$(HIPCC) --offload-arch=$(ARCH) -fPIC -pthread -shared $(BUILD)/rt_hip.o $(BUILD)/rt_shade_fast.o $(BUILD)/rt_commit.o $(BUILD)/rt_comm.o -o $(BUILD)/librt_hip.so
 	python3 tools/isa_audit.py $(DEVICE_ASM) --budget tools/spill_budget.json
 	cp $(BUILD)/librt_hip.so $@
 
@@ -71,6 +81,12 @@ sanitize: asan tsan
 	$(BUILD)/fuzz_host_asan glb 2000 4 $(BUILD)/fuzz_seeds/*.glb tests/golden/room.glb
 	$(BUILD)/fuzz_host_tsan selftest
 
+# Microbenchmarks behind the roofline limits (tools/roofline_limits.sh runs the built binaries on the GPU box).
+MICRO := tools/microbench/gather64 tools/microbench/chain tools/microbench/fetch_calib tools/microbench/mix_calib
+microbench: $(MICRO)
+tools/microbench/%: tools/microbench/%.hip
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 $< -o $@
+
 # Re-records the spill figures after a change that was looked at (tools/isa_audit.py --list shows them).
 spill-budget:
 	python3 tools/isa_audit.py $(DEVICE_ASM) --budget tools/spill_budget.json --write-budget
@@ -90,4 +106,4 @@ clean:
 	rm -rf $(BUILD)
 	rm -f $(LIBDIR)/*.so oracle/liboracle.so examples/rt_render
 
-.PHONY: all clean spill-budget asan tsan sanitize
+.PHONY: all clean spill-budget asan tsan sanitize microbench

@@ -67,6 +67,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-optin", action="store_true", help="skip the informational figures for the other settings of RT_OPT_WIDE_BVH")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample")
+    ap.add_argument("--of-spp", type=int, default=0, help="the configuration's full sample count when --spp is a bounded step of it (stated in config.workload; rates are per sample)")
     ap.add_argument("--dump-accum", default=None, help="rank 0 saves the merged fp32 sum buffer of the timed steps to this .npy file")
     return ap.parse_args()
 
@@ -273,11 +274,12 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"{args.scene} ({'procedural dragon-class mesh, ' if 'knot' in args.scene else ''}{triangles} triangles in {scene.models_count} models), "
-                            f"{args.width}x{args.height}, {args.spp} spp per {'image' if tile_split else 'GPU'} per step, primary+{args.bounces} bounces, "
+                            f"{args.width}x{args.height}, {args.spp} spp per {'image' if tile_split else 'GPU'} per step" + (f" (a step is {args.spp} of the configuration's {args.of_spp} spp; rates are per sample)" if args.of_spp else "") + f", primary+{args.bounces} bounces, "
                             f"{'Spectral' if args.spectral else 'RGB'} NEE+MIS" + (", hero-wavelength mode (4 wavelengths per camera sample; the camera ray they share is traced once and counted once)" if args.hero else "") + (", opt-in SAH trees (not the reference's traversal order)" if args.bvh == "sah" else "")
                             + (", " + TREES[wide]),
                 "sharding": (("tile-split 8x8 tiles" if tile_split else "sample-split frames") + f", scene replicated, {'RCCL' if args.dist_backend == 'nccl' else args.dist_backend} sum-reduce of the fp32 accumulation buffer") if distributed else "single GPU",
                 "rays_per_camera_sample": round(total_rays / max(total_samples, 1), 4),
+                "shadow_rays_per_camera_sample": round(st["shadow_rays"] / max(st["camera_samples"], 1), 4),
             },
             "spp_per_s": round(spp_per_s, 3),
             "camera_samples_per_s": round(total_samples / elapsed, 1),
@@ -341,6 +343,24 @@ def main():
                             "trace_only_mrays_per_s": round(wst["rays"] / max(wst["trace_ms"] / 1e3, 1e-12) / 1e6, 2)}
             be.set_option(capi.RT_OPT_WIDE_BVH, 3)
         if world == 1 and not args.no_optin:
+            # Informational, never the headline: the same steps with the opt-in fast-arithmetic shading kernels
+            # (RT_OPT_FAST_SHADE; radiance within the RMSE contract instead of bit-exact, traversal unchanged).
+            be.set_option(capi.RT_OPT_FAST_SHADE, 1)
+            step(0)
+            be.reset_stats()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for k in range(2):
+                step(1 + k)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t1
+            fst = be.stats()
+            be.set_option(capi.RT_OPT_FAST_SHADE, 0)
+            out["fast_shade_opt_in"] = {"value": round(fst["rays"] / dt / 1e6, 3), "unit": "Mrays/s", "steps": 2, "ms_per_step": round(dt / 2 * 1e3, 3),
+                                        "spp_per_s": round(fst["camera_samples"] / pixels / dt, 3),
+                                        "what": "shading and light-connection kernels built with the hardware's reciprocal / square root / transcendental instructions; "
+                                                "relative RMSE against the checker 1.3 % at 64 spp on this workload (tests/test_gpu_fast_shade.py), hit ids and distances unchanged"}
+        if world == 1 and not args.no_optin:
             # (the bench context is closed first: with its stream, torch's and the three of the new context the
             # process would hold more streams than the four hardware queues, and two of the three would share one)
             be.close()
@@ -349,7 +369,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, scene, cam, rtype)
             # The other CPU baseline, the reference's own shaders on Mesa llvmpipe, cannot be produced here.
-            out["llvmpipe"] = "unavailable (no OpenGL 3.3 context can be created on this machine: no X server, EGL or OSMesa; running the reference's shader text was also refused in the build environment)"
+            out["llvmpipe"] = llvmpipe_status()
         print(json.dumps(out), flush=True)
 
     if be is not None:
@@ -436,11 +456,43 @@ def measured_limits(args):
         return json.load(f)
 
 
+def llvmpipe_status():
+    """Why the reference's GLSL cannot be timed on Mesa llvmpipe here: what this machine offers for a headless
+    OpenGL 3.3 context, probed now, plus the standing refusal."""
+    import ctypes
+
+    found = []
+    for lib in ("libEGL.so.1", "libOSMesa.so.8", "libOSMesa.so.6", "libGL.so.1"):
+        try:
+            ctypes.CDLL(lib)
+            found.append(lib)
+        except OSError:
+            pass
+    display = os.environ.get("DISPLAY") or os.environ.get("WAYLAND_DISPLAY")
+    probe = (f"probed on this machine: loadable {', '.join(found) if found else 'none of libEGL / libOSMesa / libGL'}; "
+             f"{'display ' + display if display else 'no DISPLAY or WAYLAND_DISPLAY'}")
+    return ("unavailable (" + probe + "; and running the reference's shader text was refused in the build environment, "
+            "so no harness for it ships: the CPU figure reported is the checker's, cpu_baseline)")
+
+
+def host_threads():
+    """Threads for CPU work on this host: every core the job may use.  A GPU box reports the whole machine's
+    cores (os.cpu_count()) while a job's share is smaller and is what the *_NUM_THREADS variables carry."""
+    try:
+        allowed = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        allowed = os.cpu_count() or 1
+    share = os.environ.get("OMP_NUM_THREADS", "")
+    if share.isdigit() and int(share) > 0:
+        allowed = min(allowed, int(share))
+    return max(1, allowed)
+
+
 def cpu_baseline(args, scene, cam, rtype):
     """The CPU checker (oracle/, a port of the reference GLSL) on a bounded sample of the same workload."""
     from oracle_binding import OracleScene
 
-    threads = min(16, os.cpu_count() or 1)
+    threads = host_threads()
     orc = OracleScene(scene)
     W, H = args.width, args.height
     # Calibrate on one full 1-spp frame, then size the sample (whole frames) for ~cpu-seconds of work.
@@ -457,6 +509,7 @@ def cpu_baseline(args, scene, cam, rtype):
         "value": round(rate / 1e6, 4),
         "unit": "Mrays/s",
         "cores": threads,
+        "cores_note": f"all cores this job may use: the machine reports {os.cpu_count()}, OMP_NUM_THREADS={os.environ.get('OMP_NUM_THREADS', 'unset')}",
         "kind": "port",
         "sample": f"frames 1..{frames} of the {W}x{H} image ({frames} of the step's {args.spp} spp), {st['rays']} rays in {dt:.1f} s",
         "spp_per_s": round(st["camera_samples"] / (W * H) / max(dt, 1e-9), 5),

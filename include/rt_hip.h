@@ -75,6 +75,7 @@ typedef struct rt_stats {
     uint64_t leaf_visits;       /* leaves opened */
     uint64_t inner_phase_steps; /* steps that ran the inner-node phase */
     uint64_t refills;           /* times a wave fetched new rays for its idle lanes */
+    uint64_t shadow_rays;       /* the NEE shadow rays among `rays` (the rest are path segments) */
 } rt_stats;
 
 /* Creates a context on HIP device `device`.  Replaces the GL context +
@@ -294,10 +295,17 @@ int rt_set_counters(rt_ctx *ctx, int enabled);
  *                            quarter of the bytes; fetches (src/RayScene.cpp:337-380) return the same floats, bit for
  *                            bit, through a 256-entry table.  Textures no material refers to are not copied at
  *                            all.  0 keeps the uploaded words.  Re-commits a committed scene.  Env RT_TEX_U8.
+ *   RT_OPT_FAST_SHADE        1: the shading and light-connection kernels (traceColor's arithmetic,
+ *                            src/RayTracer.cpp:119-541 and :700-1255) run a build that uses the hardware's one-instruction
+ *                            reciprocal, square root, exponential, logarithm, sine and cosine and fused multiply-adds
+ *                            instead of the pinned, correctly rounded sequences.  Camera rays and traversal are
+ *                            untouched: hit ids, t, u, v stay bit-exact; radiance then agrees with the default
+ *                            (and the checker) only within a per-pixel relative RMSE (2 % at 64 spp is the bar the
+ *                            tests hold it to).  Default 0.  Env RT_FAST_SHADE.
  */
 enum { RT_OPT_SHADOW_EARLY_OUT = 1, RT_OPT_REFILL_LANES = 2, RT_OPT_INNER_SHARE = 3, RT_OPT_MAX_PATHS = 4, RT_OPT_TILE_MAJOR = 5,
        RT_OPT_SPECTRAL_PDF_AS_WRITTEN = 6, RT_OPT_WIDE_BVH = 7, RT_OPT_HERO_WAVELENGTH = 8, RT_OPT_NEE = 9,
-       RT_OPT_STRATIFIED = 10, RT_OPT_PIPELINE = 11, RT_OPT_TEXTURE_U8 = 12 };
+       RT_OPT_STRATIFIED = 10, RT_OPT_PIPELINE = 11, RT_OPT_TEXTURE_U8 = 12, RT_OPT_FAST_SHADE = 13 };
 int rt_set_option(rt_ctx *ctx, int option, int value);
 
 /* Facts about the committed scene as the device holds it (no reference counterpart: the reference's

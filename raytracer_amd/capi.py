@@ -22,6 +22,7 @@ RT_OPT_NEE = 9
 RT_OPT_STRATIFIED = 10
 RT_OPT_PIPELINE = 11
 RT_OPT_TEXTURE_U8 = 12
+RT_OPT_FAST_SHADE = 13
 RT_INFO_TEXTURE_BYTES_UPLOADED, RT_INFO_TEXTURE_BYTES_DEVICE, RT_INFO_TEXTURES_RGBA8, RT_INFO_TEXTURES_FP32, RT_INFO_TREE_MODE = 1, 2, 3, 4, 5
 
 # Every symbol include/rt_hip.h declares.
@@ -74,6 +75,7 @@ class RtStats(C.Structure):
         ("leaf_visits", C.c_uint64),
         ("inner_phase_steps", C.c_uint64),
         ("refills", C.c_uint64),
+        ("shadow_rays", C.c_uint64),
     ]
 
 

@@ -46,6 +46,7 @@
 #include "rt_bsdf.h"
 #include "rt_commit.h"
 #include "rt_comm.h"
+#include "rt_shade_fast.h"
 
 using namespace rtd;
 using namespace rtc;
@@ -116,6 +117,7 @@ struct rt_ctx : rt_scene_host {
     bool nee = true;
     bool stratified = true;
     uint32_t tileOffset = 0, tileStride = 1;
+    bool fastShade = false;    // RT_OPT_FAST_SHADE: shading and connection kernels built with the hardware's own arithmetic
     bool textureU8 = true;     // RT_OPT_TEXTURE_U8 / env RT_TEX_U8: 8-bit textures are kept as RGBA8 words on the device
     float *dUnorm8 = nullptr;  // [512] k / 255.0f and srgb_to_linear of it (rt_create)
     uint64_t texturesPacked8 = 0, texturesKept32 = 0, textureBytesUploaded = 0, textureBytesDevice = 0;
@@ -435,6 +437,11 @@ int runBatch(rt_ctx *ctx, const Batch &bt) {
     // Hero-wavelength mode runs the whole bounce loop once per wavelength of the camera sample.
     const int passes = (spectral && fp.hero) ? 4 : 1;
 
+    auto connect = [&](int stage) {
+        if (ctx->fastShade) rtFastConnect(spectral, gShade, ctx->stream, &ctx->view, &bt, &ctx->pb, stage, cnt, fp.shadowEarlyOut);
+        else if (spectral) hipLaunchKernelGGL(k_connect<true>, dim3(gShade), dim3(kBlock), 0, ctx->stream, ctx->view, bt, ctx->pb, stage, cnt, fp.shadowEarlyOut);
+        else hipLaunchKernelGGL(k_connect<false>, dim3(gShade), dim3(kBlock), 0, ctx->stream, ctx->view, bt, ctx->pb, stage, cnt, fp.shadowEarlyOut);
+    };
     for (int pass = 0; pass < passes; ++pass) {
         RT_HIP(hipMemsetAsync(ctx->pb.stages, 0, sizeof(Stage) * ((size_t)fp.bounces + 2), ctx->stream));
         if (spectral) hipLaunchKernelGGL(k_generate<true>, dim3(gGen), dim3(kBlock), 0, ctx->stream, fp, bt, ctx->pb, fp.hero ? pass : -1);
@@ -450,18 +457,15 @@ int runBatch(rt_ctx *ctx, const Batch &bt) {
                 launchTrace(ctx, b & 1, b, b == 0 ? paths : 2 * paths);
                 if (sameCameraRays) RT_HIP(hipMemcpyAsync(ctx->pb.cameraHits, ctx->pb.hits, (size_t)paths * sizeof(HitRec), hipMemcpyDeviceToDevice, ctx->stream));
             }
-            if (b > 0 && fp.nee) {   // without NEE there are no shadow rays to connect
-                if (spectral) hipLaunchKernelGGL(k_connect<true>, dim3(gShade), dim3(kBlock), 0, ctx->stream, ctx->view, bt, ctx->pb, b, cnt, fp.shadowEarlyOut);
-                else hipLaunchKernelGGL(k_connect<false>, dim3(gShade), dim3(kBlock), 0, ctx->stream, ctx->view, bt, ctx->pb, b, cnt, fp.shadowEarlyOut);
-            }
-            if (spectral) hipLaunchKernelGGL(k_shade_spectral, dim3(gShade), dim3(kBlock), 0, ctx->stream, ctx->view, fp, bt, ctx->pb, b, cnt);
+            if (b > 0 && fp.nee) connect(b);   // without NEE there are no shadow rays to connect
+            if (ctx->fastShade) rtFastShade(spectral, gShade, ctx->stream, &ctx->view, &fp, &bt, &ctx->pb, b, cnt);
+            else if (spectral) hipLaunchKernelGGL(k_shade_spectral, dim3(gShade), dim3(kBlock), 0, ctx->stream, ctx->view, fp, bt, ctx->pb, b, cnt);
             else hipLaunchKernelGGL(k_shade_rgb, dim3(gShade), dim3(kBlock), 0, ctx->stream, ctx->view, fp, bt, ctx->pb, b, cnt);
         }
         const int last = fp.bounces + 1;
         if (fp.nee) {
             launchTrace(ctx, -1, last, paths);
-            if (spectral) hipLaunchKernelGGL(k_connect<true>, dim3(gShade), dim3(kBlock), 0, ctx->stream, ctx->view, bt, ctx->pb, last, cnt, fp.shadowEarlyOut);
-            else hipLaunchKernelGGL(k_connect<false>, dim3(gShade), dim3(kBlock), 0, ctx->stream, ctx->view, bt, ctx->pb, last, cnt, fp.shadowEarlyOut);
+            connect(last);
         }
     }
 
@@ -577,6 +581,7 @@ int rt_create(rt_ctx **out, int device) {
         }
     }
     if (const char *env = std::getenv("RT_TEX_U8")) ctx->textureU8 = std::atoi(env) != 0;
+    if (const char *env = std::getenv("RT_FAST_SHADE")) ctx->fastShade = std::atoi(env) != 0;
     if (const char *env = std::getenv("RT_TILE_MAJOR")) ctx->planesInner = std::atoi(env) != 0;
     if (const char *env = std::getenv("RT_PIPELINE")) ctx->pipelineOn = std::atoi(env) != 0;
     if (const char *env = std::getenv("RT_WIDE_BVH")) {
@@ -1208,6 +1213,7 @@ int rt_get_stats(rt_ctx *ctx, rt_stats *out) {
     out->leaf_visits = c[8];
     out->inner_phase_steps = c[9];
     out->refills = c[10];
+    out->shadow_rays = c[11];
     return RT_OK;
 }
 
@@ -1273,6 +1279,11 @@ int rt_set_option(rt_ctx *ctx, int option, int value) {
             return RT_OK;
         case RT_OPT_PIPELINE:
             ctx->pipelineOn = value != 0;
+            return RT_OK;
+        case RT_OPT_FAST_SHADE:
+            if (rtFastLayout[0] != sizeof(SceneView) || rtFastLayout[1] != sizeof(FrameParams) || rtFastLayout[2] != sizeof(Batch) || rtFastLayout[3] != sizeof(PathBuffers))
+                return RT_ERR_STATE;   // the two translation units were built from different headers
+            ctx->fastShade = value != 0;
             return RT_OK;
         case RT_OPT_TEXTURE_U8:
             if (ctx->textureU8 == (value != 0)) return RT_OK;

@@ -664,9 +664,13 @@ __global__ __launch_bounds__(kBlock, (COUNT && kCountingWaves > 0) ? kCountingWa
             const uint32_t again = lengthOf(&st->retrace);
             if (again != 0u) atomicAdd(&pb.counters[5], (unsigned long long)again);
         } else {
-            unsigned long long total = 0;
-            for (int q = 0; q < kSubQueues; ++q) total += (qExt ? st->ext[q].count : 0u) + st->shadow[q].count;
+            unsigned long long total = 0, shadowRays = 0;
+            for (int q = 0; q < kSubQueues; ++q) {
+                total += (qExt ? st->ext[q].count : 0u) + st->shadow[q].count;
+                shadowRays += st->shadow[q].count;
+            }
             atomicAdd(&pb.counters[0], total);
+            atomicAdd(&pb.counters[11], shadowRays);
         }
     }
     if (COUNT) {

@@ -354,9 +354,13 @@ __global__ __launch_bounds__(kBlock, (COUNT && kCountingWaves > 0) ? kCountingWa
     }
 
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        unsigned long long total = 0;
-        for (int q = 0; q < kSubQueues; ++q) total += (qExt ? st->ext[q].count : 0u) + st->shadow[q].count;
+        unsigned long long total = 0, shadowRays = 0;
+        for (int q = 0; q < kSubQueues; ++q) {
+            total += (qExt ? st->ext[q].count : 0u) + st->shadow[q].count;
+            shadowRays += st->shadow[q].count;
+        }
         atomicAdd(&pb.counters[0], total);
+        atomicAdd(&pb.counters[11], shadowRays);
     }
     if (COUNT) {
         for (int off = 32; off > 0; off >>= 1) {

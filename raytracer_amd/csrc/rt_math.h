@@ -82,7 +82,15 @@ RT_FN float clampMag_(float x, float m) { return fmin_(fmax_(x, -m), m); }
 #endif
 RT_FN float clamp_(float x, float lo, float hi) { return fmin_(fmax_(x, lo), hi); }
 RT_FN float abs_(float x) { return u2f(f2u(x) & 0x7fffffffu); }
+// RT_FAST_SHADE (the opt-in shading kernels of rt_shade_fast.hip, device code only): the hardware's own
+// square root, reciprocal square root, exponential, logarithm, sine and cosine in place of the pinned
+// sequences.  Results then differ from the checker's in the last bits; the traversal never uses these.
+#if defined(RT_FAST_SHADE) && defined(__HIP_DEVICE_COMPILE__)
+#define RT_FAST_DEVICE_MATH 1
+RT_FN float sqrt_(float x) { return __builtin_amdgcn_sqrtf(x); }
+#else
 RT_FN float sqrt_(float x) { return __builtin_sqrtf(x); }
+#endif
 RT_FN float floor_(float x) { return __builtin_floorf(x); }
 RT_FN float fract_(float x) { return x - floor_(x); }
 RT_FN float mix_(float a, float b, float t) { return a * (1.0f - t) + b * t; }
@@ -95,6 +103,10 @@ RT_FN float scale2_(float z, int n) {
     return z * u2f((uint32_t)(n + 127) << 23);
 }
 
+#ifdef RT_FAST_DEVICE_MATH
+RT_FN float exp_(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+RT_FN float log_(float x) { return __builtin_amdgcn_logf(x) * 0.693147180559945309f; }
+#else
 RT_FN float exp_(float x) {
     if (x != x) return x;
     if (x > 88.7228394f) return inf();
@@ -151,6 +163,7 @@ RT_FN float log_(float x) {
     r = r + 0.693359375f * fe;
     return r;
 }
+#endif
 
 RT_FN float pow_(float x, float y) {
     if (x == 0.0f) return 0.0f;
@@ -163,6 +176,13 @@ RT_FN float pow5_(float x) {
 RT_FN float pow2_(float x) { return x * x; }
 
 // sin and cos of x (radians) for |x| up to a few thousand.
+#ifdef RT_FAST_DEVICE_MATH
+RT_FN void sincos_(float x, float *s, float *c) {
+    const float turns = x * 0.159154943091895336f;   // v_sin_f32 / v_cos_f32 take revolutions
+    *s = __builtin_amdgcn_sinf(turns);
+    *c = __builtin_amdgcn_cosf(turns);
+}
+#else
 RT_FN void sincos_(float x, float *s, float *c) {
     float k = floor_(x * 0.636619772367581343f + 0.5f);
     int q = (int)k;
@@ -185,6 +205,7 @@ RT_FN void sincos_(float x, float *s, float *c) {
         default: *s = -cs; *c = sn; break;
     }
 }
+#endif
 RT_FN float sin_(float x) { float s, c; sincos_(x, &s, &c); return s; }
 RT_FN float cos_(float x) { float s, c; sincos_(x, &s, &c); return c; }
 RT_FN float tan_(float x) { float s, c; sincos_(x, &s, &c); return s / c; }
@@ -206,7 +227,11 @@ RT_FN V3 operator-(V3 a) { return v3(-a.x, -a.y, -a.z); }
 RT_FN float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 RT_FN V3 cross(V3 a, V3 b) { return v3(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y); }
 RT_FN float length(V3 a) { return sqrt_(dot(a, a)); }
+#ifdef RT_FAST_DEVICE_MATH
+RT_FN V3 normalize(V3 a) { return a * __builtin_amdgcn_rsqf(dot(a, a)); }
+#else
 RT_FN V3 normalize(V3 a) { return a * (1.0f / sqrt_(dot(a, a))); }
+#endif
 RT_FN V3 vmin(V3 a, V3 b) { return v3(fmin_(a.x, b.x), fmin_(a.y, b.y), fmin_(a.z, b.z)); }
 RT_FN V3 vmax(V3 a, V3 b) { return v3(fmax_(a.x, b.x), fmax_(a.y, b.y), fmax_(a.z, b.z)); }
 RT_FN V3 vclamp(V3 a, float lo, float hi) { return v3(clamp_(a.x, lo, hi), clamp_(a.y, lo, hi), clamp_(a.z, lo, hi)); }

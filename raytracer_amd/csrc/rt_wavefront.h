@@ -108,7 +108,7 @@ struct PathBuffers {
     uint32_t subCap;     // capacity of one sub-queue
     Stage *stages;       // [kMaxBounces + 2]: one per bounce and the last shadow stage
     unsigned long long *counters;  // [kCounters]: 0 rays, 1 nodeVisits, 2 triTests, 3 shadedHits, 4 deepest traversal stack, 5 rays traced again,
-                                   // 6 wave steps of k_trace, 7 active lanes summed over them, 8 leaves opened, 9 steps in the inner-node phase, 10 refills
+                                   // 6 wave steps of k_trace, 7 active lanes summed over them, 8 leaves opened, 9 steps in the inner-node phase, 10 refills, 11 shadow rays (part of 0)
     // Four-wide traversal only: stack entries beyond the LDS part, [wave][overflowDepth][64].
     int32_t *overflow;
     uint32_t overflowDepth;
