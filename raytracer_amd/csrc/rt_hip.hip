@@ -302,23 +302,26 @@ int allocPathBuffers(rt_ctx *ctx, uint64_t want64) {
         RT_HIP(hipFree(ctx->pb.cameraHits));
         ctx->pb.cameraHits = nullptr;
     }
-    if ((rc = devAlloc(ctx, &ctx->pb.rays, (size_t)want * 2)) != RT_OK) return rc;
-    if ((rc = devAlloc(ctx, &ctx->pb.hits, (size_t)want * 2)) != RT_OK) return rc;
-    if ((rc = devAlloc(ctx, &ctx->pb.stA, want)) != RT_OK) return rc;
-    if ((rc = devAlloc(ctx, &ctx->pb.stB, want)) != RT_OK) return rc;
-    if ((rc = devAlloc(ctx, &ctx->pb.neeA, want)) != RT_OK) return rc;
-    if ((rc = devAlloc(ctx, &ctx->pb.neeB, want)) != RT_OK) return rc;
-    if ((rc = devAlloc(ctx, &ctx->pb.neeC, want)) != RT_OK) return rc;
-    // Re-trace list of the four-wide walk: room for every ray one launch can trace.
-    ctx->pb.retraceCap = 0;
-    if ((rc = devAlloc(ctx, &ctx->pb.retrace, (size_t)want * 2)) != RT_OK) return rc;
-    ctx->pb.retraceCap = want * 2;
     // A sub-queue receives what the blocks mapped to it produce: at most its share
     // of the paths plus one block-round of slack per block feeding it.
     const size_t maxGrid = (size_t)ctx->numCUs * 16 + kSubQueues;
     const size_t subCap = ((size_t)want + kSubQueues - 1) / kSubQueues + (maxGrid / kSubQueues + 1) * kBlock;
-    if (subCap > 0xffffffffull) return RT_ERR_INVALID;
+    const size_t Q = subCap * kSubQueues;
+    if (3 * Q > 0xffffffffull) return RT_ERR_INVALID;   // record numbers are 32 bits
     ctx->pb.subCap = (uint32_t)subCap;
+    ctx->pb.Q = (uint32_t)Q;
+    // Ray and hit records at queue positions: two extension regions (even / odd bounces) and the shadow region.
+    if ((rc = devAlloc(ctx, &ctx->pb.rays, 3 * Q)) != RT_OK) return rc;
+    if ((rc = devAlloc(ctx, &ctx->pb.hits, 3 * Q)) != RT_OK) return rc;
+    if ((rc = devAlloc(ctx, &ctx->pb.stA, want)) != RT_OK) return rc;
+    if ((rc = devAlloc(ctx, &ctx->pb.stB, want)) != RT_OK) return rc;
+    if ((rc = devAlloc(ctx, &ctx->pb.neeA, Q)) != RT_OK) return rc;
+    if ((rc = devAlloc(ctx, &ctx->pb.neeB, Q)) != RT_OK) return rc;
+    if ((rc = devAlloc(ctx, &ctx->pb.neeC, Q)) != RT_OK) return rc;     // (>= want: the hero-wavelength mode indexes it by path)
+    // Re-trace list of the four-wide walk: room for every ray one launch can trace.
+    ctx->pb.retraceCap = 0;
+    if ((rc = devAlloc(ctx, &ctx->pb.retrace, (size_t)want * 2)) != RT_OK) return rc;
+    ctx->pb.retraceCap = want * 2;
     if ((rc = devAlloc(ctx, &ctx->pb.qExt[0], subCap * kSubQueues)) != RT_OK) return rc;
     if ((rc = devAlloc(ctx, &ctx->pb.qExt[1], subCap * kSubQueues)) != RT_OK) return rc;
     if ((rc = devAlloc(ctx, &ctx->pb.qShadow, subCap * kSubQueues)) != RT_OK) return rc;
@@ -340,7 +343,8 @@ int ensurePathBuffers(rt_ctx *ctx, uint64_t wantedPaths) {
     size_t freeBytes = 0, totalBytes = 0;
     if (hipMemGetInfo(&freeBytes, &totalBytes) == hipSuccess) {
         // Path state may take up to half of what is free now (plus what it already holds).
-        const uint64_t perPath = 2 * sizeof(RayRec) + 2 * sizeof(HitRec) + 5 * sizeof(float4) + 3 * sizeof(uint32_t) + 4 + 2 * sizeof(uint32_t);   // the last: re-trace list
+        const uint64_t perPath = 3 * sizeof(RayRec) + 3 * sizeof(HitRec) + 5 * sizeof(float4) + 3 * sizeof(uint32_t) + 4 + 2 * sizeof(uint32_t) +   // the last: re-trace list
+                                 (ctx->fp.hero ? sizeof(HitRec) : 0);   // hero-wavelength mode: the camera hits kept per path
         ceiling = std::min<uint64_t>(ceiling, (freeBytes / 2 + (uint64_t)ctx->P * perPath) / perPath);
     }
     uint64_t planes = std::max<uint64_t>(1, std::min<uint64_t>(ceiling / npt, (wantedPaths + npt - 1) / npt));
@@ -452,10 +456,10 @@ int runBatch(rt_ctx *ctx, const Batch &bt) {
             // 1357-1364): the camera rays are traced for the first and their hit records kept for the other three.
             const bool sameCameraRays = passes > 1 && b == 0 && ctx->pb.cameraHits != nullptr;
             if (sameCameraRays && pass > 0) {
-                RT_HIP(hipMemcpyAsync(ctx->pb.hits, ctx->pb.cameraHits, (size_t)paths * sizeof(HitRec), hipMemcpyDeviceToDevice, ctx->stream));
+                hipLaunchKernelGGL(k_camera_hits, dim3(gGen), dim3(kBlock), 0, ctx->stream, ctx->pb, 0);
             } else {
                 launchTrace(ctx, b & 1, b, b == 0 ? paths : 2 * paths);
-                if (sameCameraRays) RT_HIP(hipMemcpyAsync(ctx->pb.cameraHits, ctx->pb.hits, (size_t)paths * sizeof(HitRec), hipMemcpyDeviceToDevice, ctx->stream));
+                if (sameCameraRays) hipLaunchKernelGGL(k_camera_hits, dim3(gGen), dim3(kBlock), 0, ctx->stream, ctx->pb, 1);
             }
             if (b > 0 && fp.nee) connect(b);   // without NEE there are no shadow rays to connect
             if (ctx->fastShade) rtFastShade(spectral, gShade, ctx->stream, &ctx->view, &fp, &bt, &ctx->pb, b, cnt);
@@ -1138,9 +1142,27 @@ int rt_trace_primary(rt_ctx *ctx, uint32_t frame, int32_t *model, int32_t *ident
     else hipLaunchKernelGGL(k_generate<false>, dim3(gGen), dim3(kBlock), 0, ctx->stream, fp, bt, ctx->pb, -1);
     launchTrace(ctx, 0, 0, fp.npt);
     RT_HIP(hipGetLastError());
+    // Hit records sit at the camera rays' queue positions; the queue entries say which path each belongs to.
     std::vector<HitRec> hits(fp.npt);
-    RT_HIP(hipMemcpyAsync(hits.data(), ctx->pb.hits, (size_t)fp.npt * sizeof(HitRec), hipMemcpyDeviceToHost, ctx->stream));
-    if ((rc = rt_sync(ctx)) != RT_OK) return rc;
+    {
+        std::vector<Stage> stage0(1);
+        std::vector<HitRec> byPosition(ctx->pb.Q);
+        std::vector<uint32_t> entries(ctx->pb.Q);
+        RT_HIP(hipMemcpyAsync(stage0.data(), ctx->pb.stages, sizeof(Stage), hipMemcpyDeviceToHost, ctx->stream));
+        RT_HIP(hipMemcpyAsync(byPosition.data(), ctx->pb.hits, (size_t)ctx->pb.Q * sizeof(HitRec), hipMemcpyDeviceToHost, ctx->stream));
+        RT_HIP(hipMemcpyAsync(entries.data(), ctx->pb.qExt[0], (size_t)ctx->pb.Q * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        if ((rc = rt_sync(ctx)) != RT_OK) return rc;
+        HitRec none;
+        none.t = 1e20f; none.u = 0.0f; none.v = 0.0f; none.id = kMiss;
+        std::fill(hits.begin(), hits.end(), none);
+        for (int sub = 0; sub < kSubQueues; ++sub) {
+            const uint32_t n = std::min(stage0[0].ext[sub].count, ctx->pb.subCap);
+            for (uint32_t i = 0; i < n; ++i) {
+                const size_t at = (size_t)sub * ctx->pb.subCap + i;
+                if (entries[at] < fp.npt) hits[entries[at]] = byPosition[at];
+            }
+        }
+    }
 
     for (uint32_t q = 0; q < fp.npt; ++q) {
         uint32_t tile = q >> 6, l = q & 63u;

@@ -31,6 +31,7 @@ __global__ __launch_bounds__(kBlock) void k_generate(FrameParams fp, Batch bt, P
     for (uint32_t base = blockIdx.x * kBlock + (threadIdx.x & ~63u); base < total; base += stride) {
         uint32_t p = base + laneId();
         bool valid = false;
+        RayRec r;
         if (p < total) {
             uint32_t k, q;
             if (bt.planesInner) {
@@ -78,17 +79,30 @@ __global__ __launch_bounds__(kBlock) void k_generate(FrameParams fp, Batch bt, P
                     float lambda = (rand_float(seed) + (float)(i * fp.ssq) + (float)j) * fp.wlDt + kWlMin;
                     pb.stA[p] = make_float4(1.0f, 1.0f, lambda, 0.0f);
                 }
-                RayRec r;
                 r.ox = fp.position.x; r.oy = fp.position.y; r.oz = fp.position.z; r.pad0 = __uint_as_float(seed);
                 r.dx = d.x; r.dy = d.y; r.dz = d.z; r.pad1 = kNeverStop;
-                pb.rays[p] = r;
             }
         }
         const uint32_t sub = blockIdx.x % kSubQueues;
-        wavePush(valid, pb.qExt[0] + (size_t)sub * pb.subCap, &pb.stages[0].ext[sub].count, p);
+        const uint32_t at = wavePush(valid, pb.qExt[0] + (size_t)sub * pb.subCap, &pb.stages[0].ext[sub].count, p);
+        if (valid) pb.rays[extRecord(pb, 0, sub, at)] = r;   // the camera ray sits where its queue entry does
     }
 }
 
+
+// Hero-wavelength mode: the camera rays' hit records of a sample's first wavelength are kept under the path's
+// number (`save`), and handed to the other three wavelengths' camera rays, whose queue positions differ (`!save`).
+__global__ __launch_bounds__(kBlock) void k_camera_hits(PathBuffers pb, int save) {
+    const uint32_t sub = blockIdx.x % kSubQueues;
+    const uint32_t n = pb.stages[0].ext[sub].count;
+    const uint32_t *q = pb.qExt[0] + (size_t)sub * pb.subCap;
+    const uint32_t stride = (gridDim.x / kSubQueues) * kBlock;
+    for (uint32_t i = (blockIdx.x / kSubQueues) * kBlock + threadIdx.x; i < n; i += stride) {
+        const uint32_t path = q[i], rec = extRecord(pb, 0, sub, i);
+        if (save) pb.cameraHits[path] = pb.hits[rec];
+        else pb.hits[rec] = pb.cameraHits[path];
+    }
+}
 
 // ---- k_resolve ---------------------------------------------------------------------------
 // Adds the batch's samples into the frame sum in sample order and, when a frame

@@ -57,15 +57,15 @@ __global__ __launch_bounds__(kBlock) void k_connect(SceneView sc, Batch bt, Path
     const uint32_t stride = (gridDim.x / kSubQueues) * kBlock;
     uint32_t shaded = 0;
     for (uint32_t i = (blockIdx.x / kSubQueues) * kBlock + threadIdx.x; i < n; i += stride) {
-        const uint32_t slot = qIn[i];
-        const uint32_t path = slot - bt.P;
+        const uint32_t path = qIn[i];
+        const uint32_t slot = shadowRecord(pb, sub, i), nee = sub * pb.subCap + i;   // ray, hit and NEE term sit at the queue position
         const HitRec h = pb.hits[slot];
-        const float4 c = pb.neeC[path];
+        const float4 c = SPECTRAL ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : pb.neeC[nee];
         // RGB: a hit nearer than distToLight - 1e-4 contributes nothing; skip its material and the
         // rest of its records (the test needs 32 of the 132 bytes a connection reads).
         if (!SPECTRAL && skipOccluded && !(h.t >= c.z - 1e-4f)) continue;
         const RayRec sr = pb.rays[slot];
-        const float4 a = pb.neeA[path], b = pb.neeB[path];
+        const float4 a = pb.neeA[nee], b = pb.neeB[nee];
         const ShadowHit s = shadowHitOf(sc, sr, h, pb.counters);
         if (h.id != kMiss) shaded++;
         const V3 sd = v3(sr.dx, sr.dy, sr.dz);
@@ -124,12 +124,12 @@ __global__ __launch_bounds__(kBlock, RT_SHADE_BLOCKS) void k_shade_rgb(SceneView
 
     for (uint32_t base = (blockIdx.x / kSubQueues) * kBlock + (threadIdx.x & ~63u); base < n; base += stride) {
         const uint32_t i = base + laneId();
-        bool wantShadow = false, wantExt = false;
         uint32_t path = 0;
         if (i < n) {
             path = qIn[i];
-            const RayRec ray = pb.rays[path];
-            const HitRec h = pb.hits[path];
+            const uint32_t rec = extRecord(pb, stage, sub, i);
+            const RayRec ray = pb.rays[rec];
+            const HitRec h = pb.hits[rec];
             // A camera path starts with throughput and previous pdf one: k_generate does not store them.
             const float4 sA = stage == 0 ? make_float4(1.0f, 1.0f, 1.0f, 1.0f) : pb.stA[path];
             float4 sB = stage == 0 ? make_float4(0.0f, 0.0f, 0.0f, ray.pad0) : pb.stB[path];   // (a camera ray carries the seed)
@@ -226,11 +226,14 @@ __global__ __launch_bounds__(kBlock, RT_SHADE_BLOCKS) void k_shade_rgb(SceneView
                                 // (s_info.t >= distToLight - 1e-4) whatever lies behind it, so the
                                 // traversal may stop at the first such hit without changing the result.
                                 sr.dx = sdir.x; sr.dy = sdir.y; sr.dz = sdir.z; sr.pad1 = fp.shadowEarlyOut ? distToLight - 1e-4f : kNeverStop;
-                                pb.rays[bt.P + path] = sr;
-                                pb.neeA[path] = make_float4(brdfDirect.x, brdfDirect.y, brdfDirect.z, cosTheta);
-                                pb.neeB[path] = make_float4(rayColor.x, rayColor.y, rayColor.z, pdfArea);
-                                pb.neeC[path] = make_float4(dot(toLight, toLight), pdfBrdfLd, distToLight, 0.0f);
-                                wantShadow = true;
+                                // (appended here, inside the branch: the lanes that send a shadow ray share one atomic, and
+                                //  the records go to the entry's position without staying in registers)
+                                const uint32_t at = wavePush(true, qShadowOut, &next->shadow[sub].count, path);
+                                const uint32_t nee = sub * pb.subCap + at;
+                                pb.rays[shadowRecord(pb, sub, at)] = sr;
+                                pb.neeA[nee] = make_float4(brdfDirect.x, brdfDirect.y, brdfDirect.z, cosTheta);
+                                pb.neeB[nee] = make_float4(rayColor.x, rayColor.y, rayColor.z, pdfArea);
+                                pb.neeC[nee] = make_float4(dot(toLight, toLight), pdfBrdfLd, distToLight, 0.0f);
                             }
                         }
                     }
@@ -271,10 +274,10 @@ __global__ __launch_bounds__(kBlock, RT_SHADE_BLOCKS) void k_shade_rgb(SceneView
                         RayRec nr;
                         nr.ox = no.x; nr.oy = no.y; nr.oz = no.z; nr.pad0 = 0.0f;
                         nr.dx = L.x; nr.dy = L.y; nr.dz = L.z; nr.pad1 = kNeverStop;
-                        pb.rays[path] = nr;
+                        const uint32_t at = wavePush(true, qOut, &next->ext[sub].count, path);
+                        pb.rays[extRecord(pb, stage + 1, sub, at)] = nr;
                         pb.stA[path] = make_float4(rayColor.x, rayColor.y, rayColor.z, prevBrdfPdf);
                         pb.stB[path] = make_float4(incoming.x, incoming.y, incoming.z, __uint_as_float(seed));
-                        wantExt = true;
                     } else if (stage == 0) {
                         // A path that ends at its first hit: nobody has written its radiance record yet, and
                         // k_connect and k_resolve read it.
@@ -283,8 +286,6 @@ __global__ __launch_bounds__(kBlock, RT_SHADE_BLOCKS) void k_shade_rgb(SceneView
                 }
             }
         }
-        wavePush(wantShadow, qShadowOut, &next->shadow[sub].count, bt.P + path);
-        wavePush(wantExt, qOut, &next->ext[sub].count, path);
     }
     if (countOn) addShadedHits(pb, shaded);
 }
@@ -303,12 +304,12 @@ __global__ __launch_bounds__(kBlock) void k_shade_spectral(SceneView sc, FramePa
 
     for (uint32_t base = (blockIdx.x / kSubQueues) * kBlock + (threadIdx.x & ~63u); base < n; base += stride) {
         const uint32_t i = base + laneId();
-        bool wantShadow = false, wantExt = false;
         uint32_t path = 0;
         if (i < n) {
             path = qIn[i];
-            const RayRec ray = pb.rays[path];
-            const HitRec h = pb.hits[path];
+            const uint32_t rec = extRecord(pb, stage, sub, i);
+            const RayRec ray = pb.rays[rec];
+            const HitRec h = pb.hits[rec];
             const float4 sA = pb.stA[path];
             float4 sB = stage == 0 ? make_float4(0.0f, 0.0f, 0.0f, ray.pad0) : pb.stB[path];   // (a camera ray carries the seed)
             float throughput = sA.x, prevBrdfPdf = sA.y;
@@ -414,10 +415,11 @@ __global__ __launch_bounds__(kBlock) void k_shade_spectral(SceneView sc, FramePa
                             RayRec sr;
                             sr.ox = so.x; sr.oy = so.y; sr.oz = so.z; sr.pad0 = 0.0f;
                             sr.dx = sdir.x; sr.dy = sdir.y; sr.dz = sdir.z; sr.pad1 = kNeverStop;
-                            pb.rays[bt.P + path] = sr;
-                            pb.neeA[path] = make_float4(brdfDirect, cosTheta, pdf, dot(toLight, toLight));
-                            pb.neeB[path] = make_float4(pdfBrdfLd, distToLight, throughput, lambda);
-                            wantShadow = true;
+                            const uint32_t at = wavePush(true, qShadowOut, &next->shadow[sub].count, path);
+                            const uint32_t nee = sub * pb.subCap + at;
+                            pb.rays[shadowRecord(pb, sub, at)] = sr;
+                            pb.neeA[nee] = make_float4(brdfDirect, cosTheta, pdf, dot(toLight, toLight));
+                            pb.neeB[nee] = make_float4(pdfBrdfLd, distToLight, throughput, lambda);
                         }
                     }
 
@@ -456,12 +458,12 @@ __global__ __launch_bounds__(kBlock) void k_shade_spectral(SceneView sc, FramePa
                         RayRec nr;
                         nr.ox = no.x; nr.oy = no.y; nr.oz = no.z; nr.pad0 = 0.0f;
                         nr.dx = L.x; nr.dy = L.y; nr.dz = L.z; nr.pad1 = kNeverStop;
-                        pb.rays[path] = nr;
+                        const uint32_t at = wavePush(true, qOut, &next->ext[sub].count, path);
+                        pb.rays[extRecord(pb, stage + 1, sub, at)] = nr;
                         pb.stA[path] = make_float4(throughput, prevBrdfPdf, lambda, 0.0f);
                         sB.x = radiance;
                         sB.w = __uint_as_float(seed);
                         pb.stB[path] = sB;
-                        wantExt = true;
                     } else if (stage == 0) {
                         // A path that ends at its first hit: nobody has written its radiance record yet, and
                         // k_connect, k_resolve and the next hero-wavelength pass read it.
@@ -472,8 +474,6 @@ __global__ __launch_bounds__(kBlock) void k_shade_spectral(SceneView sc, FramePa
                 }
             }
         }
-        wavePush(wantShadow, qShadowOut, &next->shadow[sub].count, bt.P + path);
-        wavePush(wantExt, qOut, &next->ext[sub].count, path);
     }
     if (countOn) addShadedHits(pb, shaded);
 }

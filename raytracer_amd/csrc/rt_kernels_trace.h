@@ -463,9 +463,10 @@ __global__ __launch_bounds__(kBlock, (COUNT && kCountingWaves > 0) ? kCountingWa
                 const uint32_t mine = base + (uint32_t)__popcll(idleMask & ((1ull << lane) - 1ull));
                 if (COUNT) cntRefills++;
                 if (!active && mine < n) {
-                    const uint32_t *q = (src < kSubQueues) ? qExt + (size_t)src * pb.subCap
-                                                             : pb.qShadow + (size_t)(src - kSubQueues) * pb.subCap;
-                    r.slot = q[mine];
+                    // The ray's record sits at the position of its queue entry (PathBuffers::rays): nothing to look up.
+                    // (The second walk's list holds record numbers.)
+                    if (retraceList) r.slot = qExt[mine];
+                    else r.slot = ((src < kSubQueues) ? (uint32_t)extParity * pb.Q + (uint32_t)src * pb.subCap : 2u * pb.Q + (uint32_t)(src - kSubQueues) * pb.subCap) + mine;
                     const float4 *rp = reinterpret_cast<const float4 *>(&pb.rays[r.slot]);
                     const float4 r0 = rp[0], r1 = rp[1];
                     r.ro = v3(r0.x, r0.y, r0.z);

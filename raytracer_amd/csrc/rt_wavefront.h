@@ -98,14 +98,21 @@ struct Stage {
 };
 
 struct PathBuffers {
-    RayRec *rays;        // [2P]  extension rays [0,P), shadow rays [P,2P)
-    HitRec *hits;        // [2P]
+    // Ray and hit records live at the position of the ray's queue entry, not under the path's number: record
+    // region 0 and 1 belong to the extension queues of even and odd bounces, region 2 to the shadow queue, and
+    // entry i of sub-queue j sits at region * Q + j * subCap + i (extRecord / shadowRecord below).  The kernel
+    // that appends a ray to a queue writes its record there; the traversal kernel then needs no queue entry to
+    // find the ray it was handed, and the consumers read whole lines.
+    RayRec *rays;        // [3Q]
+    HitRec *hits;        // [3Q]
     float4 *stA;         // [P]   RGB: throughput.rgb, prevBrdfPdf      Spectral: throughput, prevBrdfPdf, lambda, -
     float4 *stB;         // [P]   RGB: radiance.rgb, seed bits          Spectral: radiance, -, -, seed bits
-    float4 *neeA, *neeB, *neeC;   // [P] pending NEE term of the current bounce
+    float4 *neeA, *neeB, *neeC;   // [Q] pending NEE term of a shadow ray, at its shadow-queue position j * subCap + i
+                                  //     (Spectral uses A and B only; its hero-wavelength mode keeps a per-path sum in neeC[path])
     uint32_t *qExt[2];   // [kSubQueues * subCap] each, ping-pong by bounce parity
     uint32_t *qShadow;   // [kSubQueues * subCap]
     uint32_t subCap;     // capacity of one sub-queue
+    uint32_t Q;          // kSubQueues * subCap: records per region
     Stage *stages;       // [kMaxBounces + 2]: one per bounce and the last shadow stage
     unsigned long long *counters;  // [kCounters]: 0 rays, 1 nodeVisits, 2 triTests, 3 shadedHits, 4 deepest traversal stack, 5 rays traced again,
                                    // 6 wave steps of k_trace, 7 active lanes summed over them, 8 leaves opened, 9 steps in the inner-node phase, 10 refills, 11 shadow rays (part of 0)
@@ -131,18 +138,23 @@ __device__ __forceinline__ uint32_t laneIdNow() {
     return x;
 }
 
-// Appends `value` for every lane with `want`; one atomic per wave.  Must be
-// called by all lanes of the wave.
-__device__ __forceinline__ void wavePush(bool want, uint32_t *queue, uint32_t *count, uint32_t value) {
+// Appends `value` for every lane with `want` and returns the entry's position in the queue (undefined for the
+// other lanes); one atomic per wave.  The lanes that reach the call take part: it may sit inside a branch.
+__device__ __forceinline__ uint32_t wavePush(bool want, uint32_t *queue, uint32_t *count, uint32_t value) {
     unsigned long long mask = __ballot(want);
-    if (mask == 0ull) return;
+    if (mask == 0ull) return 0u;
     uint32_t lane = laneId();
     int leader = __ffsll((long long)mask) - 1;
     uint32_t base = 0;
     if ((int)lane == leader) base = atomicAdd(count, (uint32_t)__popcll(mask));
     base = __shfl(base, leader);
-    if (want) queue[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = value;
+    const uint32_t at = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    if (want) queue[at] = value;
+    return at;
 }
+// Where the ray and hit records of entry i of sub-queue `sub` live (see PathBuffers::rays).
+__device__ __forceinline__ uint32_t extRecord(const PathBuffers &pb, int stage, uint32_t sub, uint32_t i) { return (uint32_t)(stage & 1) * pb.Q + sub * pb.subCap + i; }
+__device__ __forceinline__ uint32_t shadowRecord(const PathBuffers &pb, uint32_t sub, uint32_t i) { return 2u * pb.Q + sub * pb.subCap + i; }
 
 // Path index -> pixel.  64 consecutive paths form one 8x8 pixel tile so a wave
 // of primary rays is spatially compact.
