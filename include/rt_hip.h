@@ -139,8 +139,10 @@ int rt_readback(rt_ctx *ctx, float *rgba_sum, size_t floats, uint32_t *frames);
  * Writes W*H RGBA8 pixels (row 0 = bottom row).  Synchronises. */
 int rt_display_rgba8(rt_ctx *ctx, uint8_t *rgba8, size_t bytes);
 
-/* rt_display_rgba8 for callers that cannot allocate (code under HIP graph capture, tight serving
- * loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same result, but the
+/* rt_display_rgba8 for callers that cannot allocate (tight serving loops, harnesses that forbid
+ * hipMalloc, code that runs between the captures of a HIP graph; the call itself launches on the
+ * context's own stream and waits for it, so it cannot be part of a capture).  No counterpart in the
+ * reference.  Same result, but the
  * RGBA8 frame is staged in a fixed 32 MiB array that every GPU the library runs on holds until the
  * process ends, instead of a buffer allocated per call: no hipMalloc/hipFree happens here.  Frames
  * of more than 8,388,608 pixels (3840x2160 fits) are refused with RT_ERR_INVALID and a message in
@@ -158,6 +160,8 @@ int rt_display_rgba8_noalloc(rt_ctx *ctx, uint8_t *rgba8, size_t bytes);
  * on the device (allocated at a slot's first use at a resolution); a slot that was begun must be ended
  * before it is begun again (RT_ERR_STATE otherwise).  `rgba8` must stay valid until the end call and
  * should be pinned host memory or device memory: a copy into pageable memory makes begin wait for it.
+ * rt_resize completes the frames in flight (their buffers hold the old size's frames) and frees every slot: an
+ * end call for a slot begun before the resize then returns RT_ERR_STATE.
  * A viewer keeps two or three frames in flight:
  *     rt_render(ctx, f, 1, 1); rt_display_rgba8_begin(ctx, f % 3, buf[f % 3], bytes);
  *     if (f >= 2) { rt_display_rgba8_end(ctx, (f - 2) % 3); present(buf[(f - 2) % 3]); }                */

@@ -359,7 +359,9 @@ int ensurePathBuffers(rt_ctx *ctx, uint64_t wantedPaths) {
     }
     // Hero-wavelength mode keeps the camera rays' hit records of a sample's first wavelength for the other three.
     // Without room for them every wavelength traces its own camera rays.
-    if (ctx->fp.hero && ctx->pb.cameraHits == nullptr && devAlloc(ctx, &ctx->pb.cameraHits, ctx->P) != RT_OK) {
+    // (RT_HERO_OWN_CAMERA_RAYS=1 forces that fallback: a testing aid)
+    static const bool ownCameraRays = std::getenv("RT_HERO_OWN_CAMERA_RAYS") != nullptr && std::atoi(std::getenv("RT_HERO_OWN_CAMERA_RAYS")) != 0;
+    if (ctx->fp.hero && !ownCameraRays && ctx->pb.cameraHits == nullptr && devAlloc(ctx, &ctx->pb.cameraHits, ctx->P) != RT_OK) {
         ctx->pb.cameraHits = nullptr;
         (void)hipGetLastError();
     }
@@ -788,6 +790,9 @@ int rt_resize(rt_ctx *ctx, int width, int height) {
     if (ctx == nullptr || width <= 0 || height <= 0 || (uint64_t)width * height > (1u << 28)) return RT_ERR_INVALID;
     RT_HIP(hipSetDevice(ctx->device));
     RT_HIP(syncAllStreams(ctx));
+    // Display frames begun at the old size have been delivered by the wait above; their slots are free again,
+    // so that a late rt_display_rgba8_end reports RT_ERR_STATE instead of passing for a frame of the new size.
+    for (rt_ctx::DisplaySlot &d : ctx->displaySlots) d.busy = false;
     ctx->W = width;
     ctx->H = height;
     const size_t px = (size_t)width * height;
@@ -872,6 +877,8 @@ static int usablePipe(rt_ctx *ctx, int pipeNo) {
         }
         pipe.pb.counters = ctx->pb.counters;
     }
+    // (the fence of the sum-buffer chain, so that the first render call on this stream creates nothing)
+    if (pipe.fence == nullptr && hipEventCreateWithFlags(&pipe.fence, hipEventDisableTiming) != hipSuccess) pipe.fence = nullptr;
     return pipeNo;
 }
 

@@ -187,5 +187,14 @@ def test_display_slots_refuse_misuse():
         assert capi.hip.rt_display_rgba8_begin(b._ctx, 0, out2.ctypes.data_as(C.c_void_p), out2.size) == capi.RT_OK
         assert capi.hip.rt_display_rgba8_end(b._ctx, 0) == capi.RT_OK
         assert np.array_equal(out2, b.display_rgba8())
+        # a frame begun before a resize is complete when the resize returns, and its slot is free: the late end call says so
+        assert capi.hip.rt_display_rgba8_begin(b._ctx, 2, out2.ctypes.data_as(C.c_void_p), out2.size) == capi.RT_OK
+        b.resize(W, H)
+        assert np.array_equal(out2, np.zeros_like(out2)) is False
+        assert capi.hip.rt_display_rgba8_end(b._ctx, 2) == capi.RT_ERR_STATE
+        b.set_frame(cam, scene.sky, capi.RT_TYPE_RGB)
+        b.render(1, 1, 1)
+        assert capi.hip.rt_display_rgba8_begin(b._ctx, 2, ptr, n) == capi.RT_OK           # and can be begun at the new size
+        assert capi.hip.rt_display_rgba8_end(b._ctx, 2) == capi.RT_OK
     finally:
         b.close()

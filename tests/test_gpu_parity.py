@@ -8,6 +8,8 @@ Bars (same seeded inputs on both sides):
     stated bar, the stricter count of differing pixels is reported too).
 """
 
+import os
+
 import numpy as np
 import pytest
 
@@ -502,6 +504,40 @@ def test_gpu_hero_wavelength_mode_matches_golden(backend, case):
         backend.set_option(capi.RT_OPT_HERO_WAVELENGTH, 0)
     assert np.array_equal(got, g["spectral"], equal_nan=True)
     assert rays == int(g["spectral_rays"]) - 3 * camera_samples   # (camera rays traced once per sample, not once per wavelength)
+
+
+def test_hero_wavelength_mode_without_room_for_the_shared_camera_hits(tmp_path):
+    """When the per-path copy of the camera rays' hit records cannot be allocated the mode traces every
+    wavelength's camera ray itself (RT_HERO_OWN_CAMERA_RAYS=1 forces that path): same image as the checker,
+    and as many rays as the checker counts.  Runs in a process of its own: the switch is read once."""
+    import subprocess
+    import sys
+    out = tmp_path / "hero.npz"
+    code = f"""
+import sys
+sys.path[:0] = [{repr(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))}, {repr(os.path.dirname(os.path.abspath(__file__)))}]
+import numpy as np
+from raytracer_amd import capi
+scene = capi.Scene("knot_glass", nu=64, nv=12)
+cam = capi.make_camera(width=56, height=40, bounces=3, ray_per_pixel=4)
+b = capi.Backend(0)
+b.set_option(capi.RT_OPT_HERO_WAVELENGTH, 1)
+b.upload_scene(scene); b.resize(56, 40); b.set_frame(cam, scene.sky, capi.RT_TYPE_SPECTRAL)
+b.render(1, 2, 1)
+img, n = b.readback()
+st = b.stats()
+np.savez({repr(str(out))}, img=img, rays=st["rays"], samples=st["camera_samples"])
+b.close()
+"""
+    env = dict(os.environ, RT_HERO_OWN_CAMERA_RAYS="1")
+    run = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, run.stderr[-800:]
+    got = np.load(out)
+    scene = capi.Scene("knot_glass", nu=64, nv=12)
+    cam = capi.make_camera(width=56, height=40, bounces=3, ray_per_pixel=4)
+    want, st = OracleScene(scene).render(cam, capi.RT_TYPE_SPECTRAL, 1, 2, 1, hero_wavelength=True)
+    assert np.array_equal(got["img"], want, equal_nan=True)
+    assert int(got["rays"]) == st["rays"]          # every wavelength's camera ray traced: nothing shared
 
 
 def test_hero_wavelength_option_is_ignored_by_the_rgb_integrator(backend):

@@ -64,3 +64,24 @@ def test_frames_beyond_the_staging_area_are_refused():
         assert np.array_equal(b.display_rgba8_noalloc(), b.display_rgba8())
     finally:
         b.close()
+
+
+def test_no_device_memory_is_taken_or_returned_by_the_call():
+    """Free device memory as the runtime reports it is the same before and after a series of calls (the
+    allocating entry point takes and returns a staging buffer per call; this one must not touch the allocator),
+    also on the first call at a new, larger resolution."""
+    import torch
+    b = capi.Backend(0)
+    try:
+        _frame(b, "cornell_quads", {}, 64, 48, 1)
+        b.display_rgba8_noalloc()                    # warm: pins nothing, but the first kernel launch loads code
+        _frame(b, "cornell_quads", {}, 640, 360, 1)  # a resolution this entry point has not seen
+        b.sync()
+        torch.cuda.synchronize()
+        free_before, _ = torch.cuda.mem_get_info(0)
+        frames = [b.display_rgba8_noalloc() for _ in range(4)]
+        free_after, _ = torch.cuda.mem_get_info(0)
+        assert free_after == free_before, f"free device memory moved by {free_before - free_after} bytes"
+        assert all(np.array_equal(f, frames[0]) for f in frames)
+    finally:
+        b.close()
