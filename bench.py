@@ -161,20 +161,52 @@ def main():
         be.set_tile_shard(rank, world)
     be.set_frame(cam, scene.sky, rtype)
 
+    # N > 1: the merge of a step's frames runs on torch's stream while the backend renders the next step.
+    # Rank 0 accumulates its own frames in `accum`, as a single GPU does, and receives the other ranks'
+    # in `others` (the running total of every merge so far); the other ranks render into two buffers in
+    # turn, so that one can be reduced (and cleared) while the other is being rendered into.  The image is
+    # accum + others on rank 0.
+    others = torch.zeros_like(accum) if distributed and rank == 0 else None
+    targets = [accum, torch.zeros_like(accum)] if distributed and rank != 0 else [accum]
+    unmerged = []   # buffers whose frames have not been reduced yet (at most one)
+
+    def merge_pending():
+        while unmerged:
+            buf = unmerged.pop()
+            reduce_accum(others if rank == 0 else buf, dist, dst=0)   # (the other ranks' buffer is cleared behind the reduce)
+
     def step(k):
+        if distributed and rank != 0:
+            cur = targets[k % 2]
+            be.bind_accum(cur.data_ptr(), cur.numel())
+        else:
+            cur = accum
         if tile_split:
             # Every rank renders all frames of the step on its own tiles (strong scaling of one image).
             be.render(first_frame=1 + k * args.spp, n_frames=args.spp, stride=1)
         else:
             # Frames of this step for this rank: sample-split over ranks, fresh frames every step.
             be.render(first_frame=1 + k * args.spp * world + rank, n_frames=args.spp, stride=world)
+        if distributed:
+            merge_pending()          # the previous step's frames, while this step's are being traced
+            unmerged.append(cur)
         be.sync()
         if distributed:
-            # Rank 0 keeps the running total; the others restart from zero so the next merge adds
-            # only new frames.  The merge runs on torch's stream: finish it before the backend's
-            # stream writes into the buffer again.
-            reduce_accum(accum, dist, dst=0)
             torch.cuda.current_stream().synchronize()
+
+    def finish():
+        """The last step's merge (nothing left to overlap it with)."""
+        if distributed:
+            merge_pending()
+            torch.cuda.current_stream().synchronize()
+
+    def clear():
+        be.reset_accum()
+        for t in targets:
+            t.zero_()
+        if others is not None:
+            others.zero_()
+        torch.cuda.synchronize()
 
     def barrier():
         if distributed:
@@ -192,19 +224,19 @@ def main():
     nodes_per_ray = cst["node_visits"] / max(cst["rays"], 1)
     tris_per_ray = cst["tri_tests"] / max(cst["rays"], 1)
     hits_per_ray = cst["shaded_hits"] / max(cst["rays"], 1)
-    be.reset_accum()
-    accum.zero_()
+    clear()
 
     for k in range(args.warmup):
         step(k)
-    be.reset_accum()
-    accum.zero_()
+    finish()
+    clear()
     be.reset_stats()
 
     barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(args.warmup + k)
+    finish()
     barrier()
     elapsed = time.perf_counter() - t0
 
@@ -216,7 +248,7 @@ def main():
         devices = gathered
     if args.dump_accum and rank == 0:
         import numpy as np
-        np.save(args.dump_accum, accum.cpu().numpy())
+        np.save(args.dump_accum, (accum + others if others is not None else accum).cpu().numpy())
     local = torch.tensor([elapsed, float(st["rays"]), float(st["camera_samples"]), st["trace_ms"], float(st["trace_launches"])],
                          dtype=torch.float64, device=f"cuda:{local_rank}")
     if distributed:
@@ -317,7 +349,7 @@ def main():
             },
             "devices": devices,
             "comm": ({"backend": "rccl" if dist.get_backend() == "nccl" else dist.get_backend(), "ranks": dist.get_world_size(),
-                      "collective": "one reduce(SUM) of the fp32 sum buffer per step, %d bytes" % (accum.numel() * 4)} if distributed else None),
+                      "collective": "one reduce(SUM) of the fp32 sum buffer per step, %d bytes, queued behind the next step's render calls so that it runs while they are traced (the last step's is not hidden)" % (accum.numel() * 4)} if distributed else None),
             "host_scene_build_s": round(t_build, 2),
             "scene_upload_commit_s": round(t_commit, 2),
         }
