@@ -313,8 +313,9 @@ int allocPathBuffers(rt_ctx *ctx, uint64_t want64) {
     // Ray and hit records at queue positions: two extension regions (even / odd bounces) and the shadow region.
     if ((rc = devAlloc(ctx, &ctx->pb.rays, 3 * Q)) != RT_OK) return rc;
     if ((rc = devAlloc(ctx, &ctx->pb.hits, 3 * Q)) != RT_OK) return rc;
-    if ((rc = devAlloc(ctx, &ctx->pb.stA, want)) != RT_OK) return rc;
-    if ((rc = devAlloc(ctx, &ctx->pb.stB, want)) != RT_OK) return rc;
+    if ((rc = devAlloc(ctx, &ctx->pb.stA, 2 * Q)) != RT_OK) return rc;
+    if ((rc = devAlloc(ctx, &ctx->pb.stB, 2 * Q)) != RT_OK) return rc;
+    if ((rc = devAlloc(ctx, &ctx->pb.radiance, want)) != RT_OK) return rc;
     if ((rc = devAlloc(ctx, &ctx->pb.neeA, Q)) != RT_OK) return rc;
     if ((rc = devAlloc(ctx, &ctx->pb.neeB, Q)) != RT_OK) return rc;
     if ((rc = devAlloc(ctx, &ctx->pb.neeC, Q)) != RT_OK) return rc;     // (>= want: the hero-wavelength mode indexes it by path)
@@ -343,7 +344,7 @@ int ensurePathBuffers(rt_ctx *ctx, uint64_t wantedPaths) {
     size_t freeBytes = 0, totalBytes = 0;
     if (hipMemGetInfo(&freeBytes, &totalBytes) == hipSuccess) {
         // Path state may take up to half of what is free now (plus what it already holds).
-        const uint64_t perPath = 3 * sizeof(RayRec) + 3 * sizeof(HitRec) + 5 * sizeof(float4) + 3 * sizeof(uint32_t) + 4 + 2 * sizeof(uint32_t) +   // the last: re-trace list
+        const uint64_t perPath = 3 * sizeof(RayRec) + 3 * sizeof(HitRec) + 8 * sizeof(float4) + 3 * sizeof(uint32_t) + 4 + 2 * sizeof(uint32_t) +   // the last: re-trace list
                                  (ctx->fp.hero ? sizeof(HitRec) : 0);   // hero-wavelength mode: the camera hits kept per path
         ceiling = std::min<uint64_t>(ceiling, (freeBytes / 2 + (uint64_t)ctx->P * perPath) / perPath);
     }
@@ -611,7 +612,7 @@ void rt_destroy(rt_ctx *ctx) {
     hipSetDevice(ctx->device);
     syncAllStreams(ctx);
     for (rt_ctx::Pipe &pipe : ctx->pipes) {
-        void *mine[] = {pipe.pb.rays, pipe.pb.hits, pipe.pb.stA, pipe.pb.stB, pipe.pb.neeA, pipe.pb.neeB, pipe.pb.neeC, pipe.pb.qExt[0], pipe.pb.qExt[1],
+        void *mine[] = {pipe.pb.rays, pipe.pb.hits, pipe.pb.stA, pipe.pb.stB, pipe.pb.radiance, pipe.pb.neeA, pipe.pb.neeB, pipe.pb.neeC, pipe.pb.qExt[0], pipe.pb.qExt[1],
                         pipe.pb.qShadow, pipe.pb.stages, pipe.pb.retrace, pipe.pb.overflow, pipe.pb.cameraHits};   // the counters belong to pipe 0
         for (void *p : mine) if (p) hipFree(p);
         if (pipe.stream) hipStreamDestroy(pipe.stream);
@@ -625,7 +626,7 @@ void rt_destroy(rt_ctx *ctx) {
     }
     for (float *p : ctx->dStream) if (p) hipFree(p);
     void *owned[] = {ctx->dNodes, ctx->dWNodes, ctx->dW8Nodes, ctx->dWPairs, ctx->pb.overflow, ctx->pb.retrace, ctx->dWTris, ctx->dTris, ctx->dShade, ctx->dUVs, ctx->dLightTris, ctx->dPrimAt, ctx->dModelDesc, ctx->dUnorm8, ctx->accumExternal ? nullptr : (void *)ctx->dAccum, ctx->dPartial,
-                     ctx->pb.rays, ctx->pb.hits, ctx->pb.stA, ctx->pb.stB, ctx->pb.neeA, ctx->pb.neeB, ctx->pb.neeC,
+                     ctx->pb.rays, ctx->pb.hits, ctx->pb.stA, ctx->pb.stB, ctx->pb.radiance, ctx->pb.neeA, ctx->pb.neeB, ctx->pb.neeC,
                      ctx->pb.qExt[0], ctx->pb.qExt[1], ctx->pb.qShadow, ctx->pb.stages, ctx->pb.counters, ctx->pb.cameraHits};
     for (void *p : owned) if (p) hipFree(p);
     drainEvents(ctx);

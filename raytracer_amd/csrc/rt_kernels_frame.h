@@ -32,6 +32,7 @@ __global__ __launch_bounds__(kBlock) void k_generate(FrameParams fp, Batch bt, P
         uint32_t p = base + laneId();
         bool valid = false;
         RayRec r;
+        float4 first = make_float4(1.0f, 1.0f, 0.0f, 0.0f);   // Spectral: the path's initial stA (throughput, previous pdf, wavelength)
         if (p < total) {
             uint32_t k, q;
             if (bt.planesInner) {
@@ -70,14 +71,15 @@ __global__ __launch_bounds__(kBlock) void k_generate(FrameParams fp, Batch bt, P
                     float4 sum = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                     if (heroPass > 0) {
                         sum = pb.neeC[p];
-                        const V3 xyz = v3(sum.x, sum.y, sum.z) + cieXYZ(pb.stA[p].z) * (pb.stB[p].x / fp.wlPdf);
+                        const float4 done = pb.radiance[p];   // the wavelength just finished: radiance, lambda
+                        const V3 xyz = v3(sum.x, sum.y, sum.z) + cieXYZ(done.y) * (done.x / fp.wlPdf);
                         sum = make_float4(xyz.x, xyz.y, xyz.z, 0.0f);
                     }
                     pb.neeC[p] = sum;
-                    pb.stA[p] = make_float4(1.0f, 1.0f, heroWavelength(heroPass, baseOffset), 0.0f);
+                    first.z = heroWavelength(heroPass, baseOffset);
                 } else if (SPECTRAL) {
                     float lambda = (rand_float(seed) + (float)(i * fp.ssq) + (float)j) * fp.wlDt + kWlMin;
-                    pb.stA[p] = make_float4(1.0f, 1.0f, lambda, 0.0f);
+                    first.z = lambda;
                 }
                 r.ox = fp.position.x; r.oy = fp.position.y; r.oz = fp.position.z; r.pad0 = __uint_as_float(seed);
                 r.dx = d.x; r.dy = d.y; r.dz = d.z; r.pad1 = kNeverStop;
@@ -85,7 +87,11 @@ __global__ __launch_bounds__(kBlock) void k_generate(FrameParams fp, Batch bt, P
         }
         const uint32_t sub = blockIdx.x % kSubQueues;
         const uint32_t at = wavePush(valid, pb.qExt[0] + (size_t)sub * pb.subCap, &pb.stages[0].ext[sub].count, p);
-        if (valid) pb.rays[extRecord(pb, 0, sub, at)] = r;   // the camera ray sits where its queue entry does
+        if (valid) {
+            const uint32_t rec = extRecord(pb, 0, sub, at);   // the camera ray sits where its queue entry does
+            pb.rays[rec] = r;
+            if (SPECTRAL) pb.stA[rec] = first;
+        }
     }
 }
 
@@ -128,9 +134,9 @@ __global__ __launch_bounds__(kBlock) void k_resolve(FrameParams fp, Batch bt, Pa
                 c = v3(pc.x, pc.y, pc.z);
             }
             const uint32_t path = pathIndex(fp, bt, k, q);
-            const float4 sB = pb.stB[path];
+            const float4 sB = pb.radiance[path];
             if (SPECTRAL) {
-                const float lambda = pb.stA[path].z;
+                const float lambda = sB.y;
                 if (fp.hero) {   // hero_wavelengths_to_rgb, src/RayTracer.cpp:1274-1280: the fourth term and the mean
                     const float4 sum = pb.neeC[path];
                     c = c + (v3(sum.x, sum.y, sum.z) + cieXYZ(lambda) * (sB.x / fp.wlPdf)) / 4.0f;

@@ -57,7 +57,9 @@ __global__ __launch_bounds__(kBlock) void k_connect(SceneView sc, Batch bt, Path
     const uint32_t stride = (gridDim.x / kSubQueues) * kBlock;
     uint32_t shaded = 0;
     for (uint32_t i = (blockIdx.x / kSubQueues) * kBlock + threadIdx.x; i < n; i += stride) {
-        const uint32_t path = qIn[i];
+        const uint32_t entry = qIn[i];
+        // Where the light's contribution goes: the record of the path's next bounce, or the finished path's radiance.
+        float4 *const target = (entry & kGoesOn) ? &pb.stB[extRecord(pb, stage, sub, entry & ~kGoesOn)] : &pb.radiance[entry];
         const uint32_t slot = shadowRecord(pb, sub, i), nee = sub * pb.subCap + i;   // ray, hit and NEE term sit at the queue position
         const HitRec h = pb.hits[slot];
         const float4 c = SPECTRAL ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : pb.neeC[nee];
@@ -83,9 +85,9 @@ __global__ __launch_bounds__(kBlock) void k_connect(SceneView sc, Batch bt, Path
                 float pdfNee = pdfArea / fmax_(G, kMinDenominator);
                 float wNee = (pdfNee * pdfNee) / fmax_(pdfNee * pdfNee + pdfBrdfLd * pdfBrdfLd, kMinDenominator);
                 V3 direct = brdfDirect * s.emissionColor * s.emissionStrength * cosTheta * G / pdfArea;
-                float4 sb = pb.stB[path];
+                float4 sb = *target;
                 V3 L = v3(sb.x, sb.y, sb.z) + rayColor * direct * wNee;
-                pb.stB[path] = make_float4(L.x, L.y, L.z, sb.w);
+                *target = make_float4(L.x, L.y, L.z, sb.w);
             }
         } else {
             const float brdfDirect = a.x, cosTheta = a.y, pdf = a.z, dist2 = a.w;
@@ -97,9 +99,9 @@ __global__ __launch_bounds__(kBlock) void k_connect(SceneView sc, Batch bt, Path
                 float wNee = (pdfNee * pdfNee) / fmax_(pdfNee * pdfNee + pdfBrdfLd * pdfBrdfLd, kMinDenominator);
                 float energy = reflectanceAt(lambda, s.emissionColor);
                 float direct = brdfDirect * energy * s.emissionStrength * cosTheta * G / pdf;
-                float4 sb = pb.stB[path];
+                float4 sb = *target;
                 sb.x = sb.x + throughput * direct * wNee;
-                pb.stB[path] = sb;
+                *target = sb;
             }
         }
         (void)c;
@@ -131,8 +133,8 @@ __global__ __launch_bounds__(kBlock, RT_SHADE_BLOCKS) void k_shade_rgb(SceneView
             const RayRec ray = pb.rays[rec];
             const HitRec h = pb.hits[rec];
             // A camera path starts with throughput and previous pdf one: k_generate does not store them.
-            const float4 sA = stage == 0 ? make_float4(1.0f, 1.0f, 1.0f, 1.0f) : pb.stA[path];
-            float4 sB = stage == 0 ? make_float4(0.0f, 0.0f, 0.0f, ray.pad0) : pb.stB[path];   // (a camera ray carries the seed)
+            const float4 sA = stage == 0 ? make_float4(1.0f, 1.0f, 1.0f, 1.0f) : pb.stA[rec];
+            float4 sB = stage == 0 ? make_float4(0.0f, 0.0f, 0.0f, ray.pad0) : pb.stB[rec];   // (a camera ray carries the seed)
             V3 rayColor = v3(sA.x, sA.y, sA.z);
             float prevBrdfPdf = sA.w;
             V3 incoming = v3(sB.x, sB.y, sB.z);
@@ -143,7 +145,7 @@ __global__ __launch_bounds__(kBlock, RT_SHADE_BLOCKS) void k_shade_rgb(SceneView
                 float t = rd.y * 0.5f + 0.5f;
                 V3 env = (1.0f - t) * v3s(1.0f) + t * fp.sky;
                 if (dot(fp.sky, fp.sky) > 0.0f) incoming = incoming + env * rayColor;
-                pb.stB[path] = make_float4(incoming.x, incoming.y, incoming.z, sB.w);
+                pb.radiance[path] = make_float4(incoming.x, incoming.y, incoming.z, 0.0f);   // the path ends here
             } else {
                 shaded++;
                 HitInfoD info = resolveHit(sc, ro, rd, h);
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(kBlock, RT_SHADE_BLOCKS) void k_shade_rgb(SceneView
                         }
                         incoming = incoming + rayColor * wBrdf * mat.emissionColor * mat.emissionStrength;
                     }
-                    pb.stB[path] = make_float4(incoming.x, incoming.y, incoming.z, sB.w);
+                    pb.radiance[path] = make_float4(incoming.x, incoming.y, incoming.z, 0.0f);   // an emitter ends the path
                 } else {
                     SurfaceRGB surf = surfaceOf(mat);
                     surf.roughness = fmax_(surf.roughness, 0.0005f);
@@ -177,6 +179,7 @@ __global__ __launch_bounds__(kBlock, RT_SHADE_BLOCKS) void k_shade_rgb(SceneView
                     const float Xi = rand_float(seed);
                     float diff = 0.0f, spec = 0.0f, sss = 0.0f;
                     bool trans = false;
+                    uint32_t *shadowEntry = nullptr;   // this bounce's shadow-queue entry, if it sends a shadow ray
                     if (Xi < lp.diffuse) {
                         L = sampleCosineHemisphere(N, seed);
                         diff = 1.0f;
@@ -229,6 +232,7 @@ __global__ __launch_bounds__(kBlock, RT_SHADE_BLOCKS) void k_shade_rgb(SceneView
                                 // (appended here, inside the branch: the lanes that send a shadow ray share one atomic, and
                                 //  the records go to the entry's position without staying in registers)
                                 const uint32_t at = wavePush(true, qShadowOut, &next->shadow[sub].count, path);
+                                shadowEntry = qShadowOut + at;
                                 const uint32_t nee = sub * pb.subCap + at;
                                 pb.rays[shadowRecord(pb, sub, at)] = sr;
                                 pb.neeA[nee] = make_float4(brdfDirect.x, brdfDirect.y, brdfDirect.z, cosTheta);
@@ -275,13 +279,14 @@ __global__ __launch_bounds__(kBlock, RT_SHADE_BLOCKS) void k_shade_rgb(SceneView
                         nr.ox = no.x; nr.oy = no.y; nr.oz = no.z; nr.pad0 = 0.0f;
                         nr.dx = L.x; nr.dy = L.y; nr.dz = L.z; nr.pad1 = kNeverStop;
                         const uint32_t at = wavePush(true, qOut, &next->ext[sub].count, path);
-                        pb.rays[extRecord(pb, stage + 1, sub, at)] = nr;
-                        pb.stA[path] = make_float4(rayColor.x, rayColor.y, rayColor.z, prevBrdfPdf);
-                        pb.stB[path] = make_float4(incoming.x, incoming.y, incoming.z, __uint_as_float(seed));
-                    } else if (stage == 0) {
-                        // A path that ends at its first hit: nobody has written its radiance record yet, and
-                        // k_connect and k_resolve read it.
-                        pb.stB[path] = make_float4(incoming.x, incoming.y, incoming.z, __uint_as_float(seed));
+                        const uint32_t to = extRecord(pb, stage + 1, sub, at);
+                        pb.rays[to] = nr;
+                        pb.stA[to] = make_float4(rayColor.x, rayColor.y, rayColor.z, prevBrdfPdf);
+                        pb.stB[to] = make_float4(incoming.x, incoming.y, incoming.z, __uint_as_float(seed));
+                        if (shadowEntry != nullptr) *shadowEntry = kGoesOn | at;   // the light's contribution follows the path
+                    } else {
+                        // The path ends: its radiance goes under its number (the shadow ray it may have sent adds to it there).
+                        pb.radiance[path] = make_float4(incoming.x, incoming.y, incoming.z, 0.0f);
                     }
                 }
             }
@@ -310,8 +315,8 @@ __global__ __launch_bounds__(kBlock) void k_shade_spectral(SceneView sc, FramePa
             const uint32_t rec = extRecord(pb, stage, sub, i);
             const RayRec ray = pb.rays[rec];
             const HitRec h = pb.hits[rec];
-            const float4 sA = pb.stA[path];
-            float4 sB = stage == 0 ? make_float4(0.0f, 0.0f, 0.0f, ray.pad0) : pb.stB[path];   // (a camera ray carries the seed)
+            const float4 sA = pb.stA[rec];
+            float4 sB = stage == 0 ? make_float4(0.0f, 0.0f, 0.0f, ray.pad0) : pb.stB[rec];   // (a camera ray carries the seed)
             float throughput = sA.x, prevBrdfPdf = sA.y;
             const float lambda = sA.z;
             float radiance = sB.x;
@@ -322,8 +327,7 @@ __global__ __launch_bounds__(kBlock) void k_shade_spectral(SceneView sc, FramePa
                 float t = rd.y * 0.5f + 0.5f;
                 V3 env = (1.0f - t) * v3s(1.0f) + t * fp.sky;
                 if (dot(fp.sky, fp.sky) > 0.0f) radiance += reflectanceAt(lambda, env) * throughput;
-                sB.x = radiance;
-                pb.stB[path] = sB;
+                pb.radiance[path] = make_float4(radiance, lambda, 0.0f, 0.0f);   // the path ends here
             } else {
                 shaded++;
                 HitInfoD info = resolveHit(sc, ro, rd, h);
@@ -346,8 +350,7 @@ __global__ __launch_bounds__(kBlock) void k_shade_spectral(SceneView sc, FramePa
                         }
                         radiance += energy * throughput * mat.emissionStrength * wBrdf;
                     }
-                    sB.x = radiance;
-                    pb.stB[path] = sB;
+                    pb.radiance[path] = make_float4(radiance, lambda, 0.0f, 0.0f);   // an emitter ends the path
                 } else {
                     if (!info.front_face) N = -N;
                     const float roughness = fmax_(mat.roughness, 0.001f);
@@ -357,6 +360,7 @@ __global__ __launch_bounds__(kBlock) void k_shade_spectral(SceneView sc, FramePa
                     const float Xi = rand_float(seed);
                     float diff = 0.0f, spec = 0.0f, sss = 0.0f;
                     bool trans = false;
+                    uint32_t *shadowEntry = nullptr;   // this bounce's shadow-queue entry, if it sends a shadow ray
                     if (Xi < lp.diffuse) {
                         L = sampleCosineHemisphere(N, seed);
                         diff = 1.0f;
@@ -416,6 +420,7 @@ __global__ __launch_bounds__(kBlock) void k_shade_spectral(SceneView sc, FramePa
                             sr.ox = so.x; sr.oy = so.y; sr.oz = so.z; sr.pad0 = 0.0f;
                             sr.dx = sdir.x; sr.dy = sdir.y; sr.dz = sdir.z; sr.pad1 = kNeverStop;
                             const uint32_t at = wavePush(true, qShadowOut, &next->shadow[sub].count, path);
+                            shadowEntry = qShadowOut + at;
                             const uint32_t nee = sub * pb.subCap + at;
                             pb.rays[shadowRecord(pb, sub, at)] = sr;
                             pb.neeA[nee] = make_float4(brdfDirect, cosTheta, pdf, dot(toLight, toLight));
@@ -459,17 +464,17 @@ __global__ __launch_bounds__(kBlock) void k_shade_spectral(SceneView sc, FramePa
                         nr.ox = no.x; nr.oy = no.y; nr.oz = no.z; nr.pad0 = 0.0f;
                         nr.dx = L.x; nr.dy = L.y; nr.dz = L.z; nr.pad1 = kNeverStop;
                         const uint32_t at = wavePush(true, qOut, &next->ext[sub].count, path);
-                        pb.rays[extRecord(pb, stage + 1, sub, at)] = nr;
-                        pb.stA[path] = make_float4(throughput, prevBrdfPdf, lambda, 0.0f);
+                        const uint32_t to = extRecord(pb, stage + 1, sub, at);
+                        pb.rays[to] = nr;
+                        pb.stA[to] = make_float4(throughput, prevBrdfPdf, lambda, 0.0f);
                         sB.x = radiance;
                         sB.w = __uint_as_float(seed);
-                        pb.stB[path] = sB;
-                    } else if (stage == 0) {
-                        // A path that ends at its first hit: nobody has written its radiance record yet, and
-                        // k_connect, k_resolve and the next hero-wavelength pass read it.
-                        sB.x = radiance;
-                        sB.w = __uint_as_float(seed);
-                        pb.stB[path] = sB;
+                        pb.stB[to] = sB;
+                        if (shadowEntry != nullptr) *shadowEntry = kGoesOn | at;   // the light's contribution follows the path
+                    } else {
+                        // The path ends: radiance and wavelength go under its number (k_connect adds the last shadow ray's
+                        // share there; k_resolve and the next hero-wavelength pass read it).
+                        pb.radiance[path] = make_float4(radiance, lambda, 0.0f, 0.0f);
                     }
                 }
             }

@@ -105,8 +105,12 @@ struct PathBuffers {
     // find the ray it was handed, and the consumers read whole lines.
     RayRec *rays;        // [3Q]
     HitRec *hits;        // [3Q]
-    float4 *stA;         // [P]   RGB: throughput.rgb, prevBrdfPdf      Spectral: throughput, prevBrdfPdf, lambda, -
-    float4 *stB;         // [P]   RGB: radiance.rgb, seed bits          Spectral: radiance, -, -, seed bits
+    // State of a path that goes on, at the position of its extension-queue entry like its ray (regions 0 and 1):
+    float4 *stA;         // [2Q]  RGB: throughput.rgb, prevBrdfPdf      Spectral: throughput, prevBrdfPdf, lambda, -
+    float4 *stB;         // [2Q]  RGB: radiance.rgb, seed bits          Spectral: radiance, -, -, seed bits
+    // What a path has gathered when it ends, under the path's number (k_resolve reads it in sample order); the
+    // light connection of a path's last bounce is added here, that of a path that goes on to its record in stB.
+    float4 *radiance;    // [P]   RGB: radiance.rgb, -                  Spectral: radiance, lambda, -, -
     float4 *neeA, *neeB, *neeC;   // [Q] pending NEE term of a shadow ray, at its shadow-queue position j * subCap + i
                                   //     (Spectral uses A and B only; its hero-wavelength mode keeps a per-path sum in neeC[path])
     uint32_t *qExt[2];   // [kSubQueues * subCap] each, ping-pong by bounce parity
@@ -154,6 +158,10 @@ __device__ __forceinline__ uint32_t wavePush(bool want, uint32_t *queue, uint32_
 }
 // Where the ray and hit records of entry i of sub-queue `sub` live (see PathBuffers::rays).
 __device__ __forceinline__ uint32_t extRecord(const PathBuffers &pb, int stage, uint32_t sub, uint32_t i) { return (uint32_t)(stage & 1) * pb.Q + sub * pb.subCap + i; }
+// Shadow-queue entries: the path's number when the path ended at the bounce that sent the shadow ray (the light's
+// contribution goes to radiance[path]), or this mark plus the position of the path's entry in the next bounce's
+// extension sub-queue of the same number (the contribution goes to that record's stB).
+constexpr uint32_t kGoesOn = 0x80000000u;
 __device__ __forceinline__ uint32_t shadowRecord(const PathBuffers &pb, uint32_t sub, uint32_t i) { return 2u * pb.Q + sub * pb.subCap + i; }
 
 // Path index -> pixel.  64 consecutive paths form one 8x8 pixel tile so a wave
