@@ -275,13 +275,13 @@ def main():
         launches = max(st["trace_launches"], 1)
         achieved = st["rays"] * b_ray / max(trace_s, 1e-12) / 1e9
         lim = measured_limits(args)
-        traffic = traffic_upper = None
+        traffic = None
         traffic_note = "not measured for this workload"
         if lim:
             per = lim["fabric_bytes_per_launch"]
-            traffic, traffic_upper = per["fetch_as_counted"] + per["write"], per["fetch_doubled"] + per["write"]
-            traffic_note = ("bytes per launch across the L2 -> fabric boundary, rocprofv3 FETCH_SIZE + WRITE_SIZE, " + LIMITS_PROFILE + "; FETCH_SIZE calibrated on known bytes "
-                            "(tools/microbench/fetch_calib): exact for the kernel's 64-byte per-lane gathers, half for 16-byte-per-lane streams, so `traffic` counts it as is and `traffic_upper` doubles it")
+            traffic = per["fetch_corrected"] + per["write"]
+            traffic_note = ("bytes per launch across the L2 -> fabric boundary: rocprofv3 FETCH_SIZE plus half of the bytes the kernel reads as wide streams (FETCH_SIZE counts those at half on gfx950, "
+                            "per-lane gathers exactly: tools/microbench/fetch_calib, mix_calib), plus WRITE_SIZE; " + LIMITS_PROFILE)
         # Lanes of the traversal kernel, from the counted pass: a wave runs one phase per step.
         steps = max(cst["wave_steps"], 1)
         lanes = {
@@ -323,17 +323,23 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": traffic,
-                "traffic_upper": traffic_upper,
                 "traffic_frac": (round(traffic / (st["trace_ms"] / launches * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if traffic else None),
                 "traffic_note": traffic_note,
                 # `frac` prices the kernel's algorithmic bytes against HBM although the caches serve most of
                 # them (it can exceed 1).  The limit that binds is the one below with the largest fraction.
                 "frac_note": "algorithmic bytes per launch / launch time / HBM peak; the L2s and the Infinity Cache serve most of these bytes, so this can reach or pass 1 and is no distance to a limit: `binding` and `limits` are",
                 "binding": (lim["binding"] if lim else None),
-                "binding_frac": (lim["limits"][lim["binding"]].get("frac", lim["limits"][lim["binding"]].get("frac_high")) if lim else None),
+                "binding_frac": (lim["limits"][lim["binding"]]["frac"] if lim else None),
                 "limits": ({k: {kk: vv for kk, vv in v.items() if kk != "what"} for k, v in lim["limits"].items()} if lim else None),
                 "limits_note": ("share of each machine limit the traversal kernel uses: VALU issue cycles, vector-L1 request rate, L2 read bandwidth, Infinity-Cache gather rate, HBM; "
                                 "rocprofv3 counters over microbenchmark or guide peaks, " + LIMITS_PROFILE.replace(".json", ".txt")) if lim else None,
+                # The counters cannot be read from inside this process: they were measured on this command by tools/roofline_limits.sh.
+                # Which build they belong to, and whether it is the library running now:
+                "limits_measured_on": ({"library_build_id": lim.get("library_build_id"), "git_commit": lim.get("git_commit"), "kernel": lim.get("kernel_full_name")} if lim else None),
+                "limits_stale": ((lim.get("library_build_id") != capi.build_id()) if lim else None),
+                "library_build_id": capi.build_id(),
+                "limits_other_kernels": ({k: {kk: v.get(kk) for kk in ("ms_per_step", "launches_per_step", "valu_issue", "lane_use", "waves_per_simd", "wait_share", "issue_wait_share", "l1_hit", "l2_hit", "fabric", "hbm")}
+                                          for k, v in lim.get("kernels", {}).items() if k in ("k_shade_rgb", "k_connect_rgb", "k_shade_spectral", "k_connect_spectral", "k_generate_rgb", "k_resolve_rgb")} if lim else None),
                 "lanes": lanes,
                 "lane_use_pmc": (lim["lane_use"] if lim else None),
                 "l1_hit": (lim["l1_hit"] if lim else None),
@@ -472,12 +478,12 @@ def one_frame_per_call(scene, rtype, device):
     return out
 
 
-LIMITS_PROFILE = "profiles/r02_i_limits.json"
+LIMITS_PROFILE = "profiles/r03_limits.json"
 
 
 def measured_limits(args):
-    """What rocprofv3's counters say about the traversal kernel of this same command (tools/roofline_limits.sh
-    + tools/roofline_report.py -> profiles/r02_i_limits.json).  Counters cannot be read from inside this
+    """What rocprofv3's counters say about the kernels of this same command (tools/roofline_limits.sh
+    + tools/roofline_report.py -> profiles/r03_limits.json, stamped with the library build it was measured on).  Counters cannot be read from inside this
     process, so the figures are the ones measured on this command; they are only reported for the default
     workload they were measured on."""
     path = os.path.join(ROOT, LIMITS_PROFILE)

@@ -10,7 +10,7 @@ TAG=${1:-cur}
 BENCH="python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-optin"
 SPEC="python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-optin --scene knot_glass --spectral"
 pass() { name=$1; counters=$2; shift 2; timeout -s KILL 200 rocprofv3 --kernel-trace --pmc $counters --output-format csv -d gpurun_out/lim_${TAG}_$name -- "$@" > gpurun_out/lim_${TAG}_$name.log 2>&1; echo "pass $name done"; }
-SQ="SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES"
+SQ="SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAVE_CYCLES"
 TC="TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum"
 python3 -c "import sys; sys.path.insert(0, '.'); from raytracer_amd import capi; print(capi.build_id())" > gpurun_out/lim_${TAG}_buildid.txt
 pass sq "$SQ" $BENCH

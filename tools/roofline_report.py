@@ -11,8 +11,9 @@ k_shade_spectral, k_connect<true> from the Spectral step):
                  SQ_ACTIVE_INST_VALU and SQ_BUSY_CYCLES: the share of issue slots the vector unit used.
   lane_use       SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU): lanes enabled per VALU instruction.
   waves_per_simd SQ_WAVE_CYCLES / SIMD-cycles the kernel was resident: waves in flight per SIMD on average.
-  wait_share     SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES: share of their resident cycles waves spend waiting for
-                 an outstanding memory (or other counted) instruction.
+  wait_share     SQ_WAIT_ANY / SQ_WAVE_CYCLES: share of their resident cycles waves spend waiting on a dependency
+                 (s_waitcnt on outstanding memory instructions, mostly); issue_wait_share is SQ_WAIT_INST_ANY /
+                 SQ_WAVE_CYCLES: cycles a wave had an instruction ready but the issue slot went to another wave.
   l1_requests    TCP_TOTAL_CACHE_ACCESSES per second / what tools/microbench/gather64 sustains from a
                  table that fits the L1 (16 KiB): the vector L1's request rate.
   l2_bandwidth   TCP_TCC_READ_REQ x 64 B per second / 34.5 TB/s (aggregate L2 read bandwidth).
@@ -117,7 +118,13 @@ model_error = max((abs(v["model_over_bytes_read"] - 1.0) for v in mix.values()),
 
 
 def family(key, prefix, pattern, stream_key):
-    sel = lambda kind: [e for e in rows(prefix + kind) if re.search(pattern, e["name"])]
+    def sel(kind):
+        # The bench command runs one untimed step with the visit counters on before the timed step: only the launches
+        # that follow the first launch of the timed traversal kernel (and the k_generate just before it) belong to the step.
+        every = rows(prefix + kind)
+        first_timed = next((i for i, e in enumerate(every) if re.search(FAMILIES[0][2], e["name"])), 0)
+        start = max((i for i in range(first_timed) if "k_generate" in every[i]["name"]), default=0)
+        return [e for e in every[start:] if re.search(pattern, e["name"])]
     sq, tc, fetch, write = sel("sq"), sel("tc"), sel("fetch"), sel("write")
     if not sq:
         return None
@@ -125,13 +132,14 @@ def family(key, prefix, pattern, stream_key):
     ms = total(sq, "ms")
     simd_cycles = total(sq, "SQ_BUSY_CYCLES") / 32 * SIMDS
     out = {"kernel": re.search(pattern, sq[0]["name"]).group(0), "mangled_or_full_name": sq[0]["name"][:160], "launches_per_step": n, "avg_launch_ms": round(ms / n, 4), "ms_per_step": round(ms, 3),
-           "vgprs": sq[0]["vgpr"], "scratch_bytes": sq[0]["scratch"], "lds_bytes_per_block": sq[0]["lds"]}
+           "vgprs": (2 * int(sq[0]["vgpr"]) if str(sq[0]["vgpr"]).isdigit() else sq[0]["vgpr"]),
+           "vgprs_note": "twice rocprofv3's VGPR_Count (it reports half of the allocation)", "scratch_bytes": sq[0]["scratch"], "lds_bytes_per_block": sq[0]["lds"]}
     out["valu_issue"] = round(total(sq, "SQ_ACTIVE_INST_VALU") * 4 / simd_cycles, 4)
     out["lane_use"] = round(total(sq, "SQ_THREAD_CYCLES_VALU") / max(64 * total(sq, "SQ_ACTIVE_INST_VALU"), 1), 4)
-    out["waves_per_simd"] = round(total(sq, "SQ_WAVE_CYCLES") / simd_cycles, 2)
-    out["wait_share"] = round(total(sq, "SQ_WAIT_INST_ANY") / max(total(sq, "SQ_WAVE_CYCLES"), 1), 4)
+    out["waves_per_simd"] = round(4 * total(sq, "SQ_WAVE_CYCLES") / simd_cycles, 2)   # (the counter ticks once per four cycles)
+    out["wait_share"] = round(total(sq, "SQ_WAIT_ANY") / max(total(sq, "SQ_WAVE_CYCLES"), 1), 4) if total(sq, "SQ_WAIT_ANY") else None
+    out["issue_wait_share"] = round(total(sq, "SQ_WAIT_INST_ANY") / max(total(sq, "SQ_WAVE_CYCLES"), 1), 4)
     out["valu_instructions_per_wave"] = round(total(sq, "SQ_INSTS_VALU") / max(total(sq, "SQ_WAVES"), 1), 1)
-    out["vmem_reads_per_wave"] = round(total(sq, "SQ_INSTS_VMEM_RD") / max(total(sq, "SQ_WAVES"), 1), 1)
     if tc:
         tc_ms = total(tc, "ms")
         l1_rate = total(tc, "TCP_TOTAL_CACHE_ACCESSES_sum") / (tc_ms * 1e-3)
@@ -247,13 +255,13 @@ with open(f"profiles/{tag}_limits.txt", "w") as f:
     for key, k in out["kernels"].items():
         fab = k.get("fabric", {})
         f.write(f"  {key:24s} {k['ms_per_step']:8.3f} ms in {k['launches_per_step']:2d} launches  vgpr {k['vgprs']:>4}  VALU issue {k['valu_issue']:.3f}  lane use {k['lane_use']:.3f}  waves/SIMD {k['waves_per_simd']:5.2f}  "
-                f"waiting {k['wait_share']:.3f}  VALU/wave {k['valu_instructions_per_wave']:8.1f}  L1 hit {k.get('l1_hit', float('nan')):.3f}  L2 hit {k.get('l2_hit', float('nan')):.3f}  "
+                f"waiting {(k['wait_share'] if k['wait_share'] is not None else float('nan')):.3f} (for an issue slot {k['issue_wait_share']:.3f})  VALU/wave {k['valu_instructions_per_wave']:8.1f}  L1 hit {k.get('l1_hit', float('nan')):.3f}  L2 hit {k.get('l2_hit', float('nan')):.3f}  "
                 f"fabric {fab.get('achieved_GBps', float('nan')):7.1f} GB/s ({fab.get('frac', float('nan')):.3f} of the gather rate, {k.get('hbm', {}).get('frac', float('nan')):.3f} of HBM)\n")
     f.write("\nper launch, raw counters:\n")
     for key, k in kernels.items():
         for a, b, c, d in k["_per_launch"]:
             f.write(f"  {key} ms={a['ms']:.3f} WAVES={a.get('SQ_WAVES', 0):.0f} VALU_inst={a.get('SQ_INSTS_VALU', 0):.0f} ACTIVE_INST_VALU={a.get('SQ_ACTIVE_INST_VALU', 0):.0f} THREAD_CYCLES_VALU={a.get('SQ_THREAD_CYCLES_VALU', 0):.0f} "
-                    f"BUSY_CYCLES={a.get('SQ_BUSY_CYCLES', 0):.0f} WAVE_CYCLES={a.get('SQ_WAVE_CYCLES', 0):.0f} WAIT_INST_ANY={a.get('SQ_WAIT_INST_ANY', 0):.0f} "
+                    f"BUSY_CYCLES={a.get('SQ_BUSY_CYCLES', 0):.0f} WAVE_CYCLES={a.get('SQ_WAVE_CYCLES', 0):.0f} WAIT_INST_ANY={a.get('SQ_WAIT_INST_ANY', 0):.0f} WAIT_ANY={a.get('SQ_WAIT_ANY', 0):.0f} "
                     f"TCP_ACCESSES={b.get('TCP_TOTAL_CACHE_ACCESSES_sum', 0):.0f} TCP_TCC_READ_REQ={b.get('TCP_TCC_READ_REQ_sum', 0):.0f} TCC_HIT={b.get('TCC_HIT_sum', 0):.0f} TCC_MISS={b.get('TCC_MISS_sum', 0):.0f} "
                     f"FETCH_KB={c.get('FETCH_SIZE', 0):.0f} WRITE_KB={d.get('WRITE_SIZE', 0):.0f}\n")
 print(open(f"profiles/{tag}_limits.txt").read()[:6000])
