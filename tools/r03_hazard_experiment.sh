@@ -4,6 +4,9 @@
 #                        `interior` scene's instance; textured_room's instance has two instructions in between)
 #   x_fixed_count0.so    the same budget, clamp as v_med3_f32
 # then the counting tests on the fixed library at the old budget.
+# The two libraries are not kept in the tree.  x_fixed_count0.so = `make EXTRA_HIPFLAGS=-DRT_WCOUNT=0` of this source;
+# x_unfixed_count0.so = the same with the clamp of 1/d in k_trace's refill written as
+# fminI_(fmaxI_(1/d, -1e18f), 1e18f) (rt_kernels_trace.h of commit 9a89d11).  Result: profiles/r03_a_hazard_experiment.txt.
 set -o pipefail
 L=raytracer_amd/lib
 mkdir -p gpurun_out
