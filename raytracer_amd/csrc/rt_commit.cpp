@@ -712,6 +712,79 @@ int buildWideNodes(rt_scene_host *ctx, std::vector<ModelDesc> &descs, std::vecto
         const double ex = (double)b[3] - b[0], ey = (double)b[4] - b[1], ez = (double)b[5] - b[2];
         return ex * ey + ey * ez + ez * ex;
     };
+    // Which binary nodes become the children of a wide node.  Default: the cut of at most four descendants that
+    // minimises the expected cost of walking the collapsed tree (surface-area heuristic over WIDE nodes, solved
+    // bottom-up: cost[n][i] = cheapest way to stand for subtree n with at most i + 1 slots of its parent; a
+    // visit of a wide node costs kNodeCost x its area, of a leaf kLeafCost x its area).  RT_COLLAPSE=greedy
+    // keeps the earlier rule: a node adopts the children of its child with the largest box until it has four.
+    // (Every leaf is visited through exactly one slot whatever the cut, so the leaves' share of the cost is the same
+    // for all cuts: only the areas of the nodes that become wide nodes decide.  Measured: any leaf weight, same trees.)
+    constexpr double kNodeCost = 1.0, kLeafCost = 0.9;
+    static const bool greedyCollapse = std::getenv("RT_COLLAPSE") != nullptr && std::strcmp(std::getenv("RT_COLLAPSE"), "greedy") == 0;
+    struct Cut { float cost[3]; uint8_t split[5]; };   // split[j], j = 2..4: slots given to the left child when j are shared out; 0 = use j - 1
+    std::vector<Cut> cuts;
+    if (!greedyCollapse) {
+        cuts.resize(bin.size());
+        std::vector<std::pair<int32_t, bool>> walk;   // (node, children done)
+        for (auto &rootOf : roots) walk.push_back({rootOf.first, false});
+        while (!walk.empty()) {
+            const auto [n, done] = walk.back();
+            walk.pop_back();
+            const BinNode &b = bin[(size_t)n];
+            Cut &c = cuts[(size_t)n];
+            if (b.leaf) {
+                const float leafCost = leafCount(n) == 0 ? 0.0f : (float)(area(n) * kLeafCost);
+                c.cost[0] = c.cost[1] = c.cost[2] = leafCost;
+                continue;
+            }
+            if (!done) {
+                walk.push_back({n, true});
+                walk.push_back({b.left, false});
+                walk.push_back({b.right, false});
+                continue;
+            }
+            const Cut &l = cuts[(size_t)b.left], &r = cuts[(size_t)b.right];
+            double share[5] = {0, 0, 0, 0, 0};   // share[j]: cheapest way to stand for both children with j slots
+            for (int j = 2; j <= 4; ++j) {
+                double best = 0.0;
+                int bestK = 0;
+                for (int k = 1; k < j; ++k) {
+                    if (k > 3 || j - k > 3) continue;
+                    const double v = (double)l.cost[k - 1] + (double)r.cost[j - k - 1];
+                    if (bestK == 0 || v < best) { best = v; bestK = k; }
+                }
+                share[j] = best;
+                c.split[j] = (uint8_t)bestK;
+            }
+            c.cost[0] = (float)(area(n) * kNodeCost + share[4]);          // one slot: a wide node of its own
+            for (int i = 1; i < 3; ++i) {
+                if ((float)share[i + 1] < c.cost[i - 1]) c.cost[i] = (float)share[i + 1];
+                else { c.cost[i] = c.cost[i - 1]; c.split[i + 1] = c.split[i + 1] | 0x80; }   // marked: fewer slots are as cheap
+            }
+        }
+    }
+    // The children of the wide node that stands for binary node n, by the cuts above.
+    auto cutChildren = [&](int32_t n, int32_t *kids) -> int {
+        int nk = 0;
+        struct Share { int32_t node; int slots; };
+        Share stack[8];
+        int sp = 0;
+        const BinNode &top = bin[(size_t)n];
+        const int k4 = cuts[(size_t)n].split[4] & 0x7f;
+        stack[sp++] = {top.right, 4 - k4};
+        stack[sp++] = {top.left, k4};
+        while (sp > 0) {
+            Share s = stack[--sp];
+            const BinNode &b = bin[(size_t)s.node];
+            // (a marked split says the subtree is as cheap with one slot fewer: step down until a real split or one slot)
+            while (!b.leaf && s.slots > 1 && (cuts[(size_t)s.node].split[s.slots] & 0x80)) --s.slots;
+            if (b.leaf || s.slots == 1) { kids[nk++] = s.node; continue; }
+            const int k = cuts[(size_t)s.node].split[s.slots] & 0x7f;
+            stack[sp++] = {b.right, s.slots - k};
+            stack[sp++] = {b.left, k};
+        }
+        return nk;
+    };
     struct Item { int32_t node; int32_t wide; int held; };   // binary node to expand, its slot, entries its ancestors keep stacked
     std::vector<Item> todo;
     struct Family { int32_t kids[4]; int count; };   // the binary nodes a wide node's children stand for
@@ -727,7 +800,8 @@ int buildWideNodes(rt_scene_host *ctx, std::vector<ModelDesc> &descs, std::vecto
         todo.pop_back();
         int32_t kids[4] = {bin[(size_t)it.node].left, bin[(size_t)it.node].right, -1, -1};
         int nk = 2;
-        while (nk < 4) {
+        if (!greedyCollapse) nk = cutChildren(it.node, kids);
+        while (greedyCollapse && nk < 4) {
             int best = -1;
             double bestArea = -1.0;
             for (int i = 0; i < nk; ++i) {
