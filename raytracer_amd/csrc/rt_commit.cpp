@@ -28,6 +28,42 @@ using namespace rtd;
 
 namespace rtc {
 
+// RT_COMMIT_TIMING=1: prints the host time since `since` under the name `what`, and restarts the clock.
+void commitLap(const char *what, std::chrono::steady_clock::time_point &since) {
+    static const bool on = std::getenv("RT_COMMIT_TIMING") != nullptr;
+    const auto now = std::chrono::steady_clock::now();
+    if (on) std::fprintf(stderr, "rt_commit_scene:   %-26s %7.1f ms\n", what, std::chrono::duration<double, std::milli>(now - since).count());
+    since = now;
+}
+
+// Host threads for building trees at commit: RT_BUILD_THREADS, else the machine's, at most 16.
+int buildThreads() {
+    if (const char *env = std::getenv("RT_BUILD_THREADS")) return std::min(std::max(std::atoi(env), 1), 64);
+    return (int)std::min(std::max(std::thread::hardware_concurrency(), 1u), 16u);
+}
+
+// Joins every thread it holds when it goes out of scope, so that an exception thrown while threads
+// are running (an allocation failure in the spawning loop or in the caller's own share of the work)
+// unwinds past joined threads instead of ending the process in ~thread.
+struct ThreadGroup {
+    std::vector<std::thread> threads;
+    explicit ThreadGroup(size_t expected) { threads.reserve(expected); }
+    ~ThreadGroup() { join(); }
+    void join() {
+        for (std::thread &t : threads)
+            if (t.joinable()) t.join();
+    }
+    // False when the system has no thread to give: the caller does that piece itself.
+    template <typename Fn, typename... Args> bool spawn(Fn &&fn, Args &&...args) {
+        try {
+            threads.emplace_back(std::forward<Fn>(fn), std::forward<Args>(args)...);
+            return true;
+        } catch (const std::system_error &) {
+            return false;
+        }
+    }
+};
+
 // Builds the traversal re-pack from the uploaded model streams and validates
 // every offset the kernels will follow.
 int repackScene(rt_scene_host *ctx, std::vector<PackedNode> &nodes, std::vector<PackedTri> &tris, std::vector<PackedShade> &shade, std::vector<PackedUV> &uvs, std::vector<LightTri> &lightTris, std::vector<ModelDesc> &descs) {
@@ -116,55 +152,77 @@ int repackScene(rt_scene_host *ctx, std::vector<PackedNode> &nodes, std::vector<
             lightTris.push_back(lt);
         }
 
-        // Triangles in identifier (leaf) order.
-        for (int t = 0; t < d.identifiersCount; ++t) {
-            int at = d.identBase + t * kIdentWords;
-            if (!checkIdent(at)) return RT_ERR_SCENE;
-            int idx[3] = {f2i(mdl[at]), f2i(mdl[at + 1]), f2i(mdl[at + 2])};
-            int material = f2i(mdl[at + 3]);
-            bool hasTextures = mdl[at + 4] != 0.0f;
-            const float *A = &mdl[(size_t)d.vertBase + (size_t)idx[0] * 8];
-            const float *B = &mdl[(size_t)d.vertBase + (size_t)idx[1] * 8];
-            const float *C = &mdl[(size_t)d.vertBase + (size_t)idx[2] * 8];
-            PackedTri pt;
-            for (int k = 0; k < 3; ++k) {
-                pt.a[k] = A[k];
-                pt.ab[k] = B[k] - A[k];
-                pt.ac[k] = C[k] - A[k];
-            }
-            pt.material = material;
-            pt.model = m;
-            pt.ident = t;
-            if (hasTextures) {
-                int baseColor = f2i(mats[(size_t)material * kMaterialWords + 1]);
-                float alphaCut = mats[(size_t)material * kMaterialWords + 20];
-                if (baseColor != -1 && alphaCut > 0.0f) {
-                    pt.model |= kTriAlphaTest;
-                    ctx->hasAlphaTest = true;
+        // Triangles in identifier (leaf) order; a large model's are shared among host threads (every triangle's
+        // records depend on its own identifier and vertices only).
+        {
+            const size_t first = tris.size(), count = (size_t)d.identifiersCount;
+            tris.resize(first + count);
+            shade.resize(first + count);
+            uvs.resize(first + count);
+            std::atomic<bool> malformed{false}, alphaTest{false};
+            auto pack = [&](size_t t0, size_t t1) {
+                for (size_t t = t0; t < t1; ++t) {
+                    const int at = d.identBase + (int)t * kIdentWords;
+                    if (!checkIdent(at)) { malformed = true; return; }
+                    const int idx[3] = {f2i(mdl[at]), f2i(mdl[at + 1]), f2i(mdl[at + 2])};
+                    const int material = f2i(mdl[at + 3]);
+                    const bool hasTextures = mdl[at + 4] != 0.0f;
+                    const float *A = &mdl[(size_t)d.vertBase + (size_t)idx[0] * 8];
+                    const float *B = &mdl[(size_t)d.vertBase + (size_t)idx[1] * 8];
+                    const float *C = &mdl[(size_t)d.vertBase + (size_t)idx[2] * 8];
+                    PackedTri pt;
+                    for (int k = 0; k < 3; ++k) {
+                        pt.a[k] = A[k];
+                        pt.ab[k] = B[k] - A[k];
+                        pt.ac[k] = C[k] - A[k];
+                    }
+                    pt.material = material;
+                    pt.model = m;
+                    pt.ident = (int32_t)t;
+                    if (hasTextures) {
+                        const int baseColor = f2i(mats[(size_t)material * kMaterialWords + 1]);
+                        const float alphaCut = mats[(size_t)material * kMaterialWords + 20];
+                        if (baseColor != -1 && alphaCut > 0.0f) {
+                            pt.model |= kTriAlphaTest;
+                            alphaTest = true;
+                        }
+                    }
+                    tris[first + t] = pt;
+                    PackedShade ps{};
+                    for (int k = 0; k < 3; ++k) {
+                        ps.n0[k] = A[3 + k];
+                        ps.n1[k] = B[3 + k];
+                        ps.n2[k] = C[3 + k];
+                    }
+                    // (the same single-precision operations, in the same order, as the kernels would run on every hit)
+                    const V3 geometric = cross(v3(pt.ab[0], pt.ab[1], pt.ab[2]), v3(pt.ac[0], pt.ac[1], pt.ac[2]));
+                    ps.geometric[0] = geometric.x; ps.geometric[1] = geometric.y; ps.geometric[2] = geometric.z;
+                    ps.area = 0.5f * length(geometric);
+                    ps.material = material;
+                    ps.model = m;
+                    ps.hasTextures = hasTextures ? 1 : 0;
+                    shade[first + t] = ps;
+                    PackedUV pu{};
+                    for (int k = 0; k < 2; ++k) {
+                        pu.uv0[k] = A[6 + k];
+                        pu.uv1[k] = B[6 + k];
+                        pu.uv2[k] = C[6 + k];
+                    }
+                    uvs[first + t] = pu;
                 }
+            };
+            const int workers = count >= 65536 ? buildThreads() : 1;
+            {
+                ThreadGroup pool((size_t)workers);
+                for (int w = 1; w < workers; ++w) {
+                    const size_t t0 = count * (size_t)w / (size_t)workers, t1 = count * (size_t)(w + 1) / (size_t)workers;
+                    if (!pool.spawn(pack, t0, t1)) pack(t0, t1);
+                }
+                pack(0, count / (size_t)workers);
+                pool.join();
             }
-            tris.push_back(pt);
-            PackedShade ps{};
-            for (int k = 0; k < 3; ++k) {
-                ps.n0[k] = A[3 + k];
-                ps.n1[k] = B[3 + k];
-                ps.n2[k] = C[3 + k];
-            }
-            // (the same single-precision operations, in the same order, as the kernels would run on every hit)
-            const V3 geometric = cross(v3(pt.ab[0], pt.ab[1], pt.ab[2]), v3(pt.ac[0], pt.ac[1], pt.ac[2]));
-            ps.geometric[0] = geometric.x; ps.geometric[1] = geometric.y; ps.geometric[2] = geometric.z;
-            ps.area = 0.5f * length(geometric);
-            ps.material = material;
-            ps.model = m;
-            ps.hasTextures = hasTextures ? 1 : 0;
-            shade.push_back(ps);
-            PackedUV pu{};
-            for (int k = 0; k < 2; ++k) {
-                pu.uv0[k] = A[6 + k];
-                pu.uv1[k] = B[6 + k];
-                pu.uv2[k] = C[6 + k];
-            }
-            uvs.push_back(pu);
+            if (malformed) return RT_ERR_SCENE;
+            if (alphaTest) ctx->hasAlphaTest = true;
         }
 
         // Inner nodes get consecutive packed indices in original node order.
@@ -319,42 +377,6 @@ void packTextures(const rt_scene_host *ctx, bool enable, TexturePack &out) {
             std::memcpy(&out.materials[(size_t)m * kMaterialWords + k], &movedTo[i], 4);
         }
 }
-
-// RT_COMMIT_TIMING=1: prints the host time since `since` under the name `what`, and restarts the clock.
-void commitLap(const char *what, std::chrono::steady_clock::time_point &since) {
-    static const bool on = std::getenv("RT_COMMIT_TIMING") != nullptr;
-    const auto now = std::chrono::steady_clock::now();
-    if (on) std::fprintf(stderr, "rt_commit_scene:   %-26s %7.1f ms\n", what, std::chrono::duration<double, std::milli>(now - since).count());
-    since = now;
-}
-
-// Host threads for building trees at commit: RT_BUILD_THREADS, else the machine's, at most 16.
-int buildThreads() {
-    if (const char *env = std::getenv("RT_BUILD_THREADS")) return std::min(std::max(std::atoi(env), 1), 64);
-    return (int)std::min(std::max(std::thread::hardware_concurrency(), 1u), 16u);
-}
-
-// Joins every thread it holds when it goes out of scope, so that an exception thrown while threads
-// are running (an allocation failure in the spawning loop or in the caller's own share of the work)
-// unwinds past joined threads instead of ending the process in ~thread.
-struct ThreadGroup {
-    std::vector<std::thread> threads;
-    explicit ThreadGroup(size_t expected) { threads.reserve(expected); }
-    ~ThreadGroup() { join(); }
-    void join() {
-        for (std::thread &t : threads)
-            if (t.joinable()) t.join();
-    }
-    // False when the system has no thread to give: the caller does that piece itself.
-    template <typename Fn, typename... Args> bool spawn(Fn &&fn, Args &&...args) {
-        try {
-            threads.emplace_back(std::forward<Fn>(fn), std::forward<Args>(args)...);
-            return true;
-        } catch (const std::system_error &) {
-            return false;
-        }
-    }
-};
 
 // Binary tree over one model's triangles by binned surface-area splits (16 bins per axis on the
 // triangle centres), for RT_OPT_WIDE_BVH 2 and 3.  Nodes are emitted (root first) through `emit(box,
@@ -638,22 +660,49 @@ int binaryTreesOfModels(rt_scene_host *ctx, std::vector<ModelDesc> &descs, const
     for (size_t i = 0; i < wtris.size(); ++i) wtris[i].ident = (int32_t)i;
     commitLap("triangle copy", mark);
     using Bin = BinNode;
-    for (ModelDesc &d : descs) {
-        d.wideRootRef = d.rootRef;   // a tree that is one leaf: same reference, wtris being a copy of tris there
-        if (d.nodesCount <= 0) continue;
-        if (rebuild && d.identifiersCount > 0) {
-            // The library's own tree over the model's triangles: binned surface-area splits, leaves
-            // of one or two triangles, a copy of the triangle records in its leaf order.
-            const int32_t base = (int32_t)bin.size();
+    // The library's own trees (binned surface-area splits, leaves of one or two triangles, a copy of the triangle
+    // records in leaf order) are built side by side, one model per thread on top of each build's own threads
+    // (a single build does not keep sixteen cores busy), each into nodes of its own with child numbers relative
+    // to its root; they are strung together in model order below.
+    std::vector<std::vector<Bin>> own(descs.size());
+    std::vector<char> failed(descs.size(), 0);
+    if (rebuild) {
+        auto build = [&](size_t m) {
+            const ModelDesc &d = descs[m];
+            std::vector<Bin> &nodes = own[m];
             if (!sahTree(mdl, d, tris, wtris, [&](const float *box, int32_t left, int32_t right, int32_t leafRef, bool leaf) {
                     Bin b{};
                     for (int k = 0; k < 6; ++k) b.box[k] = box[k];
-                    b.left = leaf ? -1 : base + left;
-                    b.right = leaf ? -1 : base + right;
+                    b.left = leaf ? -1 : left;
+                    b.right = leaf ? -1 : right;
                     b.leafRef = leafRef;
                     b.leaf = leaf;
-                    bin.push_back(b);
-                })) return RT_ERR_SCENE;
+                    nodes.push_back(b);
+                })) failed[m] = 1;
+        };
+        std::vector<size_t> jobs;
+        for (size_t m = 0; m < descs.size(); ++m)
+            if (descs[m].nodesCount > 0 && descs[m].identifiersCount > 0) jobs.push_back(m);
+        ThreadGroup pool(jobs.size());
+        const bool sideBySide = jobs.size() > 1 && buildThreads() > 1;
+        for (size_t j = 1; j < jobs.size(); ++j)
+            if (!sideBySide || !pool.spawn(build, jobs[j])) build(jobs[j]);
+        if (!jobs.empty()) build(jobs[0]);
+        pool.join();
+        for (size_t m = 0; m < descs.size(); ++m)
+            if (failed[m]) return RT_ERR_SCENE;
+    }
+    for (size_t m = 0; m < descs.size(); ++m) {
+        ModelDesc &d = descs[m];
+        d.wideRootRef = d.rootRef;   // a tree that is one leaf: same reference, wtris being a copy of tris there
+        if (d.nodesCount <= 0) continue;
+        if (rebuild && d.identifiersCount > 0) {
+            const int32_t base = (int32_t)bin.size();
+            for (Bin b : own[m]) {
+                if (!b.leaf) { b.left += base; b.right += base; }
+                bin.push_back(b);
+            }
+            std::vector<Bin>().swap(own[m]);
             if (bin[(size_t)base].leaf) {
                 d.wideRootRef = bin[(size_t)base].leafRef;
                 continue;
@@ -725,8 +774,9 @@ int buildWideNodes(rt_scene_host *ctx, std::vector<ModelDesc> &descs, std::vecto
     std::vector<Cut> cuts;
     if (!greedyCollapse) {
         cuts.resize(bin.size());
-        std::vector<std::pair<int32_t, bool>> walk;   // (node, children done)
-        for (auto &rootOf : roots) walk.push_back({rootOf.first, false});
+        // (one tree per thread: a tree's nodes are its own)
+        auto solve = [&](int32_t root) {
+        std::vector<std::pair<int32_t, bool>> walk{{root, false}};   // (node, children done)
         while (!walk.empty()) {
             const auto [n, done] = walk.back();
             walk.pop_back();
@@ -762,6 +812,13 @@ int buildWideNodes(rt_scene_host *ctx, std::vector<ModelDesc> &descs, std::vecto
                 else { c.cost[i] = c.cost[i - 1]; c.split[i + 1] = c.split[i + 1] | 0x80; }   // marked: fewer slots are as cheap
             }
         }
+        };
+        ThreadGroup pool(roots.size());
+        const bool threaded = bin.size() >= 65536 && buildThreads() > 1;
+        for (size_t k = 1; k < roots.size(); ++k)
+            if (!threaded || !pool.spawn(solve, roots[k].first)) solve(roots[k].first);
+        solve(roots[0].first);
+        pool.join();
     }
     // The children of the wide node that stands for binary node n, by the cuts above.
     auto cutChildren = [&](int32_t n, int32_t *kids) -> int {
