@@ -50,10 +50,15 @@ $(BUILD)/rt_shade_fast.o: $(CSRC)/rt_shade_fast.hip $(wildcard $(CSRC)/*.h)
 	cd $(BUILD) && $(HIPCC) $(FASTFLAGS) -save-temps -c $(CURDIR)/$(CSRC)/rt_shade_fast.hip -o rt_shade_fast.o
 	python3 tools/isa_audit.py $(FAST_ASM)
 
-$(LIBDIR)/librt_hip.so: $(BUILD)/rt_shade_fast.o $(CSRC)/rt_hip.hip $(wildcard $(CSRC)/*.h) include/rt_hip.h $(BUILD)/rt_commit.o $(BUILD)/rt_comm.o tools/isa_audit.py tools/spill_budget.json
+# The device-side tree build (hipcub radix sort): a translation unit of its own, the sort's templates take a while.
+$(BUILD)/rt_tree_device.o: $(CSRC)/rt_tree_device.hip $(CSRC)/rt_tree_device.h $(CSRC)/rt_commit.h $(CSRC)/rt_device.h include/rt_hip.h
+	@mkdir -p $(BUILD)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(LIBDIR)/librt_hip.so: $(BUILD)/rt_tree_device.o $(BUILD)/rt_shade_fast.o $(CSRC)/rt_hip.hip $(wildcard $(CSRC)/*.h) include/rt_hip.h $(BUILD)/rt_commit.o $(BUILD)/rt_comm.o tools/isa_audit.py tools/spill_budget.json
 	@mkdir -p $(LIBDIR) $(BUILD)
 	cd $(BUILD) && $(HIPCC) $(subst -Iinclude,-I$(CURDIR)/include,$(subst -I$(CSRC),-I$(CURDIR)/$(CSRC),$(HIPFLAGS))) $(EXTRA_HIPFLAGS) -DRT_BUILD_ID='"$(BUILD_ID)"' -save-temps -c $(CURDIR)/$(CSRC)/rt_hip.hip -o rt_hip.o
-	$(HIPCC) --offload-arch=$(ARCH) -fPIC -pthread -shared $(BUILD)/rt_hip.o $(BUILD)/rt_shade_fast.o $(BUILD)/rt_commit.o $(BUILD)/rt_comm.o -o $(BUILD)/librt_hip.so
+	$(HIPCC) --offload-arch=$(ARCH) -fPIC -pthread -shared $(BUILD)/rt_hip.o $(BUILD)/rt_shade_fast.o $(BUILD)/rt_tree_device.o $(BUILD)/rt_commit.o $(BUILD)/rt_comm.o -o $(BUILD)/librt_hip.so
 	python3 tools/isa_audit.py $(DEVICE_ASM) --budget tools/spill_budget.json
 	cp $(BUILD)/librt_hip.so $@
 

@@ -309,7 +309,8 @@ int rt_set_counters(rt_ctx *ctx, int enabled);
  */
 enum { RT_OPT_SHADOW_EARLY_OUT = 1, RT_OPT_REFILL_LANES = 2, RT_OPT_INNER_SHARE = 3, RT_OPT_MAX_PATHS = 4, RT_OPT_TILE_MAJOR = 5,
        RT_OPT_SPECTRAL_PDF_AS_WRITTEN = 6, RT_OPT_WIDE_BVH = 7, RT_OPT_HERO_WAVELENGTH = 8, RT_OPT_NEE = 9,
-       RT_OPT_STRATIFIED = 10, RT_OPT_PIPELINE = 11, RT_OPT_TEXTURE_U8 = 12, RT_OPT_FAST_SHADE = 13 };
+       RT_OPT_STRATIFIED = 10, RT_OPT_PIPELINE = 11, RT_OPT_TEXTURE_U8 = 12, RT_OPT_FAST_SHADE = 13, RT_OPT_TREE_BUILD = 14 };
+enum { RT_TREE_BUILD_HOST = 0, RT_TREE_BUILD_DEVICE = 1 };
 int rt_set_option(rt_ctx *ctx, int option, int value);
 
 /* Facts about the committed scene as the device holds it (no reference counterpart: the reference's

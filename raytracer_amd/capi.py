@@ -23,6 +23,8 @@ RT_OPT_STRATIFIED = 10
 RT_OPT_PIPELINE = 11
 RT_OPT_TEXTURE_U8 = 12
 RT_OPT_FAST_SHADE = 13
+RT_OPT_TREE_BUILD = 14
+RT_TREE_BUILD_HOST, RT_TREE_BUILD_DEVICE = 0, 1
 RT_INFO_TEXTURE_BYTES_UPLOADED, RT_INFO_TEXTURE_BYTES_DEVICE, RT_INFO_TEXTURES_RGBA8, RT_INFO_TEXTURES_FP32, RT_INFO_TREE_MODE = 1, 2, 3, 4, 5
 
 # Every symbol include/rt_hip.h declares.

@@ -636,9 +636,7 @@ bool sahTree(const std::vector<float> &mdl, const ModelDesc &d, const std::vecto
     return true;
 }
 
-// Binary trees of all models in one array, as the collapse into wide nodes reads them: box, children
-// (indices into the array), or the leaf reference.
-struct BinNode { float box[6]; int32_t left, right; int32_t leafRef; bool leaf; };
+// Binary trees of all models in one array (children are indices into the array).
 struct BinaryTrees {
     std::vector<BinNode> bin;
     std::vector<std::pair<int32_t, ModelDesc *>> roots;   // root node and model of every tree that is more than one leaf
@@ -683,6 +681,25 @@ int binaryTreesOfModels(rt_scene_host *ctx, std::vector<ModelDesc> &descs, const
         std::vector<size_t> jobs;
         for (size_t m = 0; m < descs.size(); ++m)
             if (descs[m].nodesCount > 0 && descs[m].identifiersCount > 0) jobs.push_back(m);
+        if (ctx->deviceTree != nullptr) {
+            // Trees from the device, one model after the other (each build fills the device by itself); the
+            // triangle records are put in the leaf order it reports.
+            std::vector<int32_t> order;
+            for (size_t m : jobs) {
+                const ModelDesc &d = descs[m];
+                const int rc = ctx->deviceTree(ctx, d, own[m], order);
+                if (rc != RT_OK) return rc;
+                if (order.size() != (size_t)d.identifiersCount) return RT_ERR_SCENE;
+                for (int i = 0; i < d.identifiersCount; ++i) {
+                    const int32_t at = d.triBase + order[(size_t)i];
+                    PackedTri pt = tris[(size_t)at];
+                    pt.ident = at;
+                    wtris[(size_t)d.triBase + (size_t)i] = pt;
+                }
+            }
+            jobs.clear();
+            commitLap("binary trees on the device", mark);
+        }
         ThreadGroup pool(jobs.size());
         const bool sideBySide = jobs.size() > 1 && buildThreads() > 1;
         for (size_t j = 1; j < jobs.size(); ++j)
@@ -768,7 +785,7 @@ int buildWideNodes(rt_scene_host *ctx, std::vector<ModelDesc> &descs, std::vecto
     // keeps the earlier rule: a node adopts the children of its child with the largest box until it has four.
     // (Every leaf is visited through exactly one slot whatever the cut, so the leaves' share of the cost is the same
     // for all cuts: only the areas of the nodes that become wide nodes decide.  Measured: any leaf weight, same trees.)
-    constexpr double kNodeCost = 1.0, kLeafCost = 0.9;
+    constexpr double kNodeCost = kWideNodeCost, kLeafCost = kWideLeafCost;
     static const bool greedyCollapse = std::getenv("RT_COLLAPSE") != nullptr && std::strcmp(std::getenv("RT_COLLAPSE"), "greedy") == 0;
     struct Cut { float cost[3]; uint8_t split[5]; };   // split[j], j = 2..4: slots given to the left child when j are shared out; 0 = use j - 1
     std::vector<Cut> cuts;

@@ -8,6 +8,15 @@
 #include "rt_hip.h"      // status codes, slot numbers
 #include "rt_device.h"   // record layouts shared with the kernels
 
+namespace rtc {
+// A node of a model's binary tree as the collapse into wide nodes reads it: box, children (node numbers), or the
+// leaf reference ~((first triangle << 2) | triangle count).
+struct BinNode { float box[6]; int32_t left, right; int32_t leafRef; bool leaf; };
+// What a visit of a wide node / of a leaf costs, per unit of its surface, when the collapse chooses which binary
+// nodes become the children of a wide node (buildWideNodes; the device build uses the same figures).
+constexpr double kWideNodeCost = 1.0, kWideLeafCost = 0.9;
+}  // namespace rtc
+
 // The part of a context the commit-time code reads and writes; rt_ctx derives from it.
 struct rt_scene_host {
     std::vector<float> host[6];     // uploaded words per slot (1..5)
@@ -17,6 +26,9 @@ struct rt_scene_host {
     std::vector<int32_t> hPrimAt;   // word offset of every analytic primitive's record in the objects stream
     int maxTreeDepth = 0;           // deepest uploaded tree
     bool hasAlphaTest = false;      // some triangle needs the alpha-cut texture test
+    // Set by the owner of a device: builds one model's binary tree there instead of on the host threads (child
+    // numbers relative to the root, leaves naming places of `order`; see rt_tree_device.h).  Null: host build.
+    int (*deviceTree)(rt_scene_host *ctx, const rtd::ModelDesc &model, std::vector<rtc::BinNode> &nodes, std::vector<int32_t> &order) = nullptr;
     // result of buildWideNodes / buildWide8
     int wideStackNeed = 0;          // most stack entries a ray can hold in the wide tree
 };

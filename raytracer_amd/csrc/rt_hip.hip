@@ -47,6 +47,7 @@
 #include "rt_commit.h"
 #include "rt_comm.h"
 #include "rt_shade_fast.h"
+#include "rt_tree_device.h"
 
 using namespace rtd;
 using namespace rtc;
@@ -118,6 +119,7 @@ struct rt_ctx : rt_scene_host {
     bool stratified = true;
     uint32_t tileOffset = 0, tileStride = 1;
     bool fastShade = false;    // RT_OPT_FAST_SHADE: shading and connection kernels built with the hardware's own arithmetic
+    bool treeOnDevice = false; // RT_OPT_TREE_BUILD / env RT_TREE_BUILD=device: the models' binary trees are built by rt_tree_device.hip
     bool textureU8 = true;     // RT_OPT_TEXTURE_U8 / env RT_TEX_U8: 8-bit textures are kept as RGBA8 words on the device
     float *dUnorm8 = nullptr;  // [512] k / 255.0f and srgb_to_linear of it (rt_create)
     uint64_t texturesPacked8 = 0, texturesKept32 = 0, textureBytesUploaded = 0, textureBytesDevice = 0;
@@ -588,6 +590,7 @@ int rt_create(rt_ctx **out, int device) {
         }
     }
     if (const char *env = std::getenv("RT_TEX_U8")) ctx->textureU8 = std::atoi(env) != 0;
+    if (const char *env = std::getenv("RT_TREE_BUILD")) ctx->treeOnDevice = std::strcmp(env, "device") == 0;
     if (const char *env = std::getenv("RT_FAST_SHADE")) ctx->fastShade = std::atoi(env) != 0;
     if (const char *env = std::getenv("RT_TILE_MAJOR")) ctx->planesInner = std::atoi(env) != 0;
     if (const char *env = std::getenv("RT_PIPELINE")) ctx->pipelineOn = std::atoi(env) != 0;
@@ -644,6 +647,13 @@ int rt_upload(rt_ctx *ctx, int slot, const void *data, size_t bytes) {
     ctx->dirty = true;
     ctx->committed = false;
     return RT_OK;
+}
+
+// rt_scene_host::deviceTree of a context whose model stream is on its device.
+static int deviceTreeOfModel(rt_scene_host *host, const ModelDesc &d, std::vector<rtc::BinNode> &nodes, std::vector<int32_t> &order) {
+    rt_ctx *ctx = static_cast<rt_ctx *>(host);
+    const rttree::ModelTriangles model{ctx->dStream[RT_SLOT_MODELS], d.identBase, d.vertBase, d.identifiersCount, d.triBase};
+    return rttree::buildBinaryTree(ctx->stream, model, nodes, order, ctx->hipError);
 }
 
 static int commitScene(rt_ctx *ctx, int objectCount, int modelsCount, int lightSourcesCount);
@@ -708,7 +718,28 @@ static int commitScene(rt_ctx *ctx, int objectCount, int modelsCount, int lightS
     ctx->wideNow = tris.empty() ? 0 : ctx->wideBvh;   // nothing to build over analytic primitives alone
     // The eight-wide kernel has no alpha-cut phase: scenes with alpha-cut textures walk the four-wide trees.
     if (ctx->wideNow == 4 && ctx->hasAlphaTest) ctx->wideNow = 3;
-    if (ctx->wideNow) {
+    ctx->deviceTree = ctx->treeOnDevice ? deviceTreeOfModel : nullptr;
+    if ((rc = devAlloc(ctx, &ctx->dTris, tris.size())) != RT_OK) return rc;
+    if (!tris.empty()) RT_HIP(hipMemcpy(ctx->dTris, tris.data(), tris.size() * sizeof(PackedTri), hipMemcpyHostToDevice));
+    // Four-wide trees and their leaves made on the device from the uploaded streams (the eight-wide trees take the
+    // device's binary trees through the host's collapse).
+    const bool wideOnDevice = ctx->treeOnDevice && (ctx->wideNow == 2 || ctx->wideNow == 3);
+    rttree::WideTrees deviceWide;
+    if (wideOnDevice) {
+        std::vector<rttree::ModelTriangles> models;
+        for (const ModelDesc &d : descs)
+            models.push_back({ctx->dStream[RT_SLOT_MODELS], d.identBase, d.vertBase, (d.nodesCount > 0 && d.identifiersCount > 0) ? d.identifiersCount : 0, d.triBase});
+        rc = rttree::buildWideTrees(ctx->stream, models, ctx->dTris, ctx->hasAlphaTest, deviceWide, ctx->hipError);
+        if (rc == RT_ERR_SCENE && !ctx->wideChosen) ctx->wideNow = 0;
+        else if (rc != RT_OK) return rc;
+        if (rc == RT_OK) {
+            for (size_t m = 0; m < descs.size(); ++m) {
+                ModelDesc &d = descs[m];
+                d.wideRootRef = models[m].count > 0 ? deviceWide.rootRefs[m] : d.rootRef;   // (no triangles: as the host build leaves it)
+            }
+            ctx->wideStackNeed = deviceWide.stackNeed;
+        }
+    } else if (ctx->wideNow) {
         rc = ctx->wideNow == 4 ? buildWide8(ctx, descs, w8nodes, tris, wtris) : buildWideNodes(ctx, descs, wnodes, tris, wtris);
         // A scene the wide build cannot take (coordinates beyond its box arithmetic, NaN) is
         // walked in the reference's order, as it would be with the option off, unless the caller
@@ -717,9 +748,25 @@ static int commitScene(rt_ctx *ctx, int objectCount, int modelsCount, int lightS
         else if (rc != RT_OK) return rc;
     }
     std::vector<TriPair> wpairs;
-    if (ctx->wideNow >= 1 && ctx->wideNow <= 3 && !ctx->hasAlphaTest) pairLeaves(wnodes, descs, wtris, wpairs);
+    if (!wideOnDevice && ctx->wideNow >= 1 && ctx->wideNow <= 3 && !ctx->hasAlphaTest) pairLeaves(wnodes, descs, wtris, wpairs);
     lap("wide trees", mark);
-    if (ctx->wideNow) {
+    if (ctx->wideNow && wideOnDevice) {
+        // (the device build's buffers become the context's; a scene is walked by pairs or, with alpha-cut textures, by triangles)
+        if (ctx->dWNodes) RT_HIP(hipFree(ctx->dWNodes));
+        ctx->dWNodes = deviceWide.nodes;
+        deviceWide.nodes = nullptr;
+        if (ctx->hasAlphaTest) {
+            if (ctx->dWTris) RT_HIP(hipFree(ctx->dWTris));
+            ctx->dWTris = deviceWide.leafTris;
+            deviceWide.leafTris = nullptr;
+            if ((rc = devAlloc(ctx, &ctx->dWPairs, 0)) != RT_OK) return rc;
+        } else {
+            if (ctx->dWPairs) RT_HIP(hipFree(ctx->dWPairs));
+            ctx->dWPairs = deviceWide.pairs;
+            deviceWide.pairs = nullptr;
+            if ((rc = devAlloc(ctx, &ctx->dWTris, 0)) != RT_OK) return rc;
+        }
+    } else if (ctx->wideNow) {
         if ((rc = devAlloc(ctx, &ctx->dWPairs, wpairs.size())) != RT_OK) return rc;
         if (!wpairs.empty()) RT_HIP(hipMemcpy(ctx->dWPairs, wpairs.data(), wpairs.size() * sizeof(TriPair), hipMemcpyHostToDevice));
         if ((rc = devAlloc(ctx, &ctx->dWTris, wtris.size())) != RT_OK) return rc;
@@ -728,6 +775,8 @@ static int commitScene(rt_ctx *ctx, int objectCount, int modelsCount, int lightS
         if (!wnodes.empty()) RT_HIP(hipMemcpy(ctx->dWNodes, wnodes.data(), wnodes.size() * sizeof(WideNode), hipMemcpyHostToDevice));
         if ((rc = devAlloc(ctx, &ctx->dW8Nodes, w8nodes.size())) != RT_OK) return rc;
         if (!w8nodes.empty()) RT_HIP(hipMemcpy(ctx->dW8Nodes, w8nodes.data(), w8nodes.size() * sizeof(Wide8Node), hipMemcpyHostToDevice));
+    }
+    if (ctx->wideNow) {
         // Stack entries that do not fit in LDS: one column per lane of every wave the grid can hold
         // (4-byte entries beyond kWideStack for the four-wide walk, 8-byte entries beyond kWide8Stack for the eight-wide).
         const bool eight = ctx->wideNow == 4;
@@ -745,7 +794,6 @@ static int commitScene(rt_ctx *ctx, int objectCount, int modelsCount, int lightS
         ctx->pb.overflowDepth = ctx->overflowWords / (eight ? 2u : 1u);   // entries per lane the kernels may index
     }
     if ((rc = devAlloc(ctx, &ctx->dNodes, nodes.size())) != RT_OK) return rc;
-    if ((rc = devAlloc(ctx, &ctx->dTris, tris.size())) != RT_OK) return rc;
     if ((rc = devAlloc(ctx, &ctx->dShade, shade.size())) != RT_OK) return rc;
     if (!shade.empty()) RT_HIP(hipMemcpy(ctx->dShade, shade.data(), shade.size() * sizeof(PackedShade), hipMemcpyHostToDevice));
     if ((rc = devAlloc(ctx, &ctx->dUVs, uvs.size())) != RT_OK) return rc;
@@ -756,7 +804,6 @@ static int commitScene(rt_ctx *ctx, int objectCount, int modelsCount, int lightS
     if (!ctx->hPrimAt.empty()) RT_HIP(hipMemcpy(ctx->dPrimAt, ctx->hPrimAt.data(), ctx->hPrimAt.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     if ((rc = devAlloc(ctx, &ctx->dModelDesc, descs.size())) != RT_OK) return rc;
     if (!nodes.empty()) RT_HIP(hipMemcpy(ctx->dNodes, nodes.data(), nodes.size() * sizeof(PackedNode), hipMemcpyHostToDevice));
-    if (!tris.empty()) RT_HIP(hipMemcpy(ctx->dTris, tris.data(), tris.size() * sizeof(PackedTri), hipMemcpyHostToDevice));
     if (!descs.empty()) RT_HIP(hipMemcpy(ctx->dModelDesc, descs.data(), descs.size() * sizeof(ModelDesc), hipMemcpyHostToDevice));
     ctx->hTris.swap(tris);
     lap("packed upload", mark);
@@ -1320,6 +1367,13 @@ int rt_set_option(rt_ctx *ctx, int option, int value) {
             ctx->textureU8 = value != 0;
             if (!ctx->committed) return RT_OK;
             ctx->dirty = true;   // the device copy of the textures belongs to the committed scene
+            return rt_commit_scene(ctx, ctx->objectCount, ctx->modelsCount, ctx->lightSourcesCount);
+        case RT_OPT_TREE_BUILD:
+            if (value != RT_TREE_BUILD_HOST && value != RT_TREE_BUILD_DEVICE) return RT_ERR_INVALID;
+            if (ctx->treeOnDevice == (value == RT_TREE_BUILD_DEVICE)) return RT_OK;
+            ctx->treeOnDevice = value == RT_TREE_BUILD_DEVICE;
+            if (!ctx->committed) return RT_OK;
+            ctx->dirty = true;
             return rt_commit_scene(ctx, ctx->objectCount, ctx->modelsCount, ctx->lightSourcesCount);
         case RT_OPT_WIDE_BVH:
             if (value < 0 || value > 4) return RT_ERR_INVALID;
