@@ -398,6 +398,33 @@ def main():
                                         "spp_per_s": round(fst["camera_samples"] / pixels / dt, 3),
                                         "what": "shading and light-connection kernels built with the hardware's reciprocal / square root / transcendental instructions; "
                                                 "relative RMSE against the checker 1.3 % at 64 spp on this workload (tests/test_gpu_fast_shade.py), hit ids and distances unchanged"}
+        if world == 1 and not args.no_optin and wide in (2, 3):
+            # Informational: the same scene with the library's trees built on the device (RT_OPT_TREE_BUILD): what the
+            # second commit takes and what tracing the other trees costs.  Same image bit for bit (tests/test_gpu_tree_device.py).
+            t1 = time.perf_counter()
+            be.set_option(capi.RT_OPT_TREE_BUILD, capi.RT_TREE_BUILD_DEVICE)   # commits the scene again
+            torch.cuda.synchronize()
+            t_device_commit = time.perf_counter() - t1
+            be.set_frame(cam, scene.sky, rtype)
+            step(0)
+            be.reset_stats()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for k in range(2):
+                step(1 + k)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t1
+            tst = be.stats()
+            t1 = time.perf_counter()
+            be.set_option(capi.RT_OPT_TREE_BUILD, capi.RT_TREE_BUILD_HOST)
+            torch.cuda.synchronize()
+            t_host_commit = time.perf_counter() - t1
+            be.set_frame(cam, scene.sky, rtype)
+            out["tree_build_device_opt_in"] = {"value": round(tst["rays"] / dt / 1e6, 3), "unit": "Mrays/s", "steps": 2, "ms_per_step": round(dt / 2 * 1e3, 3),
+                                               "commit_s": round(t_device_commit, 3), "commit_s_host_trees": round(t_host_commit, 3),
+                                               "what": "commit = validation, re-pack, tree build and uploads of a scene whose streams are already in the context "
+                                                       "(rt_upload's copy is not in it); device: Morton order + locally-ordered clustering + four-wide nodes on the GPU, "
+                                                       "host: binned surface-area trees on the host threads"}
         if world == 1 and not args.no_optin:
             # (the bench context is closed first: with its stream, torch's and the three of the new context the
             # process would hold more streams than the four hardware queues, and two of the three would share one)

@@ -306,6 +306,18 @@ int rt_set_counters(rt_ctx *ctx, int enabled);
  *                            untouched: hit ids, t, u, v stay bit-exact; radiance then agrees with the default
  *                            (and the checker) only within a per-pixel relative RMSE (2 % at 64 spp is the bar the
  *                            tests hold it to).  Default 0.  Env RT_FAST_SHADE.
+ *   RT_OPT_TREE_BUILD        RT_TREE_BUILD_DEVICE: the trees of RT_OPT_WIDE_BVH 2 to 4 are built on the device
+ *                            from the uploaded model stream -- triangles sorted along a Morton curve, neighbouring
+ *                            clusters of that order merged bottom-up by least surface, and for values 2 and 3 the
+ *                            four-wide nodes and their leaves made there as well, level by level, so that only counts
+ *                            travel to the host (value 4 takes the device's binary trees through the host's collapse).
+ *                            RT_TREE_BUILD_HOST (default): the host threads' binned surface-area trees.  The
+ *                            reference builds its trees on the CPU when a model is loaded (src/BVHTree.cpp:6-85);
+ *                            that uploaded tree is never replaced, both settings only choose who builds the
+ *                            library's own.  Same images bit for bit (closest hits do not depend on the tree;
+ *                            ties are re-traced under value 3 and 4 as before).  Measured: commit of 872 k triangles
+ *                            0.31 s -> 0.05 s, of 3.5 M triangles 0.73 s -> 0.15 s; tracing 0.4 to 1.5 % slower
+ *                            (6 % more node visits).  Re-commits a committed scene.  Env RT_TREE_BUILD=device.
  */
 enum { RT_OPT_SHADOW_EARLY_OUT = 1, RT_OPT_REFILL_LANES = 2, RT_OPT_INNER_SHARE = 3, RT_OPT_MAX_PATHS = 4, RT_OPT_TILE_MAJOR = 5,
        RT_OPT_SPECTRAL_PDF_AS_WRITTEN = 6, RT_OPT_WIDE_BVH = 7, RT_OPT_HERO_WAVELENGTH = 8, RT_OPT_NEE = 9,

@@ -12,6 +12,8 @@
 
 #include <algorithm>
 #include <array>
+#include <sys/mman.h>
+
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -64,9 +66,21 @@ struct ThreadGroup {
     }
 };
 
+void *allocateRecords(size_t bytes) {
+    void *p = nullptr;
+    if (bytes >= ((size_t)4 << 20)) {
+        if (posix_memalign(&p, (size_t)2 << 20, bytes) != 0) throw std::bad_alloc();
+        (void)madvise(p, bytes, MADV_HUGEPAGE);   // advice only: without huge pages the array is an ordinary one
+    } else {
+        p = std::malloc(bytes ? bytes : 1);
+        if (p == nullptr) throw std::bad_alloc();
+    }
+    return p;
+}
+
 // Builds the traversal re-pack from the uploaded model streams and validates
 // every offset the kernels will follow.
-int repackScene(rt_scene_host *ctx, std::vector<PackedNode> &nodes, std::vector<PackedTri> &tris, std::vector<PackedShade> &shade, std::vector<PackedUV> &uvs, std::vector<LightTri> &lightTris, std::vector<ModelDesc> &descs) {
+int repackScene(rt_scene_host *ctx, PackedNodes &nodes, PackedTris &tris, PackedShades &shade, PackedUVs &uvs, std::vector<LightTri> &lightTris, std::vector<ModelDesc> &descs) {
     const std::vector<float> &info = ctx->host[RT_SLOT_MODEL_INFO];
     const std::vector<float> &mdl = ctx->host[RT_SLOT_MODELS];
     const std::vector<float> &mats = ctx->host[RT_SLOT_MATERIALS];
@@ -107,6 +121,18 @@ int repackScene(rt_scene_host *ctx, std::vector<PackedNode> &nodes, std::vector<
     if ((size_t)ctx->modelsCount * 4 > info.size()) return RT_ERR_SCENE;
     if (ctx->lightSourcesCount < 0 || ctx->lightSourcesCount > ctx->modelsCount) return RT_ERR_SCENE;
     descs.resize((size_t)ctx->modelsCount);
+    {   // room for every model's records at once: growing model by model would copy the earlier ones again and again
+        uint64_t triangles = 0, treeNodes = 0;
+        for (int m = 0; m < ctx->modelsCount; ++m) {
+            triangles += (uint64_t)std::max(f2i(info[(size_t)m * 4 + 0]), 0);
+            treeNodes += (uint64_t)std::max(f2i(info[(size_t)m * 4 + 2]), 0);
+        }
+        if (triangles >= (1u << 29) || treeNodes * kNodeWords > mdl.size()) return RT_ERR_SCENE;
+        tris.reserve((size_t)triangles);
+        shade.reserve((size_t)triangles);
+        uvs.reserve((size_t)triangles);
+        nodes.reserve((size_t)treeNodes / 2 + 1);
+    }
 
     for (int m = 0; m < ctx->modelsCount; ++m) {
         ModelDesc d{};
@@ -154,6 +180,7 @@ int repackScene(rt_scene_host *ctx, std::vector<PackedNode> &nodes, std::vector<
 
         // Triangles in identifier (leaf) order; a large model's are shared among host threads (every triangle's
         // records depend on its own identifier and vertices only).
+        auto mark = std::chrono::steady_clock::now();
         {
             const size_t first = tris.size(), count = (size_t)d.identifiersCount;
             tris.resize(first + count);
@@ -224,14 +251,38 @@ int repackScene(rt_scene_host *ctx, std::vector<PackedNode> &nodes, std::vector<
             if (malformed) return RT_ERR_SCENE;
             if (alphaTest) ctx->hasAlphaTest = true;
         }
+        if (d.identifiersCount >= 65536) commitLap("triangle records", mark);
 
-        // Inner nodes get consecutive packed indices in original node order.
+        // Inner nodes get consecutive packed indices in original node order.  One pass in node order checks that
+        // the stream holds a tree, not a graph -- children come after their parent (no cycles) and every node has at
+        // most one parent (a node shared by two parents would make a 32-level graph 2^32 nodes large for anything that
+        // walks it as a tree) -- and finds every node's depth (a child's from its parent's, which precedes it); the
+        // traversal stack holds at most depth entries.
         std::vector<int32_t> packedIndex((size_t)d.nodesCount, -1);
         const int32_t innerBase = (int32_t)nodes.size();
         int32_t innerCount = 0;
         auto nodeWord = [&](int n, int w) { return mdl[(size_t)d.nodeBase + (size_t)n * kNodeWords + w]; };
-        for (int n = 0; n < d.nodesCount; ++n)
-            if (nodeWord(n, 8) == 0.0f) packedIndex[(size_t)n] = innerBase + innerCount++;
+        {
+            std::vector<uint8_t> depth((size_t)d.nodesCount, 0);   // 0: not reachable from node 0; 255 stands for "too deep"
+            std::vector<char> hasParent((size_t)d.nodesCount, 0);
+            if (d.nodesCount > 0) depth[0] = 1;
+            int maxDepth = d.nodesCount > 0 ? 1 : 0;
+            for (int n = 0; n < d.nodesCount; ++n) {
+                if (nodeWord(n, 8) != 0.0f) continue;
+                packedIndex[(size_t)n] = innerBase + innerCount++;
+                const int l = f2i(nodeWord(n, 6)), r = f2i(nodeWord(n, 7));
+                if (l <= n || r <= n || l >= d.nodesCount || r >= d.nodesCount || l == r) return RT_ERR_SCENE;
+                if (hasParent[(size_t)l] || hasParent[(size_t)r]) return RT_ERR_SCENE;
+                hasParent[(size_t)l] = hasParent[(size_t)r] = 1;
+                if (depth[(size_t)n] != 0) {
+                    const int below = std::min((int)depth[(size_t)n] + 1, 255);
+                    depth[(size_t)l] = depth[(size_t)r] = (uint8_t)below;
+                    maxDepth = std::max(maxDepth, below);
+                }
+            }
+            if (maxDepth > kStackDepth) return RT_ERR_SCENE;
+            ctx->maxTreeDepth = std::max(ctx->maxTreeDepth, maxDepth);
+        }
         auto childRef = [&](int n, int32_t &ref) -> bool {
             if (n < 0 || n >= d.nodesCount) return false;
             if (nodeWord(n, 8) != 0.0f) {
@@ -246,42 +297,36 @@ int repackScene(rt_scene_host *ctx, std::vector<PackedNode> &nodes, std::vector<
             return true;
         };
         nodes.resize((size_t)innerBase + (size_t)innerCount);
-        // A tree, not a graph: children come after their parent (no cycles) and every node has at
-        // most one parent (a node shared by two parents would make a 32-level graph 2^32 nodes
-        // large for anything that walks it as a tree).
-        std::vector<char> hasParent((size_t)d.nodesCount, 0);
-        for (int n = 0; n < d.nodesCount; ++n) {
-            if (nodeWord(n, 8) != 0.0f) continue;
-            int l = f2i(nodeWord(n, 6)), r = f2i(nodeWord(n, 7));
-            if (l <= n || r <= n || l >= d.nodesCount || r >= d.nodesCount || l == r) return RT_ERR_SCENE;
-            if (hasParent[(size_t)l] || hasParent[(size_t)r]) return RT_ERR_SCENE;
-            hasParent[(size_t)l] = hasParent[(size_t)r] = 1;
-            PackedNode pn{};
-            if (!childRef(l, pn.left) || !childRef(r, pn.right)) return RT_ERR_SCENE;
-            for (int k = 0; k < 3; ++k) {
-                pn.lmin[k] = nodeWord(l, k);
-                pn.lmax[k] = nodeWord(l, 3 + k);
-                pn.rmin[k] = nodeWord(r, k);
-                pn.rmax[k] = nodeWord(r, 3 + k);
+        // The packed nodes: every inner node's record depends on its own two children only.
+        {
+            std::atomic<bool> malformed{false};
+            auto packNodes = [&](int n0, int n1) {
+                for (int n = n0; n < n1; ++n) {
+                    if (nodeWord(n, 8) != 0.0f) continue;
+                    const int l = f2i(nodeWord(n, 6)), r = f2i(nodeWord(n, 7));
+                    PackedNode pn{};
+                    if (!childRef(l, pn.left) || !childRef(r, pn.right)) { malformed = true; return; }
+                    for (int k = 0; k < 3; ++k) {
+                        pn.lmin[k] = nodeWord(l, k);
+                        pn.lmax[k] = nodeWord(l, 3 + k);
+                        pn.rmin[k] = nodeWord(r, k);
+                        pn.rmax[k] = nodeWord(r, 3 + k);
+                    }
+                    nodes[(size_t)packedIndex[(size_t)n]] = pn;
+                }
+            };
+            const int workers = d.nodesCount >= 65536 ? buildThreads() : 1;
+            ThreadGroup pool((size_t)workers);
+            for (int w = 1; w < workers; ++w) {
+                const int n0 = (int)((int64_t)d.nodesCount * w / workers), n1 = (int)((int64_t)d.nodesCount * (w + 1) / workers);
+                if (!pool.spawn(packNodes, n0, n1)) packNodes(n0, n1);
             }
-            nodes[(size_t)packedIndex[(size_t)n]] = pn;
+            packNodes(0, (int)((int64_t)d.nodesCount / workers));
+            pool.join();
+            if (malformed) return RT_ERR_SCENE;
         }
-        if (d.nodesCount > 0) {
-            if (!childRef(0, d.rootRef)) return RT_ERR_SCENE;
-            // Depth bound: the traversal stack holds at most depth entries.
-            std::vector<std::pair<int, int>> todo{{0, 1}};
-            int maxDepth = 0;
-            while (!todo.empty()) {
-                auto [n, depth] = todo.back();
-                todo.pop_back();
-                maxDepth = std::max(maxDepth, depth);
-                if (nodeWord(n, 8) != 0.0f) continue;
-                todo.push_back({f2i(nodeWord(n, 6)), depth + 1});
-                todo.push_back({f2i(nodeWord(n, 7)), depth + 1});
-            }
-            if (maxDepth > kStackDepth) return RT_ERR_SCENE;
-            ctx->maxTreeDepth = std::max(ctx->maxTreeDepth, maxDepth);
-        }
+        if (d.nodesCount > 0 && !childRef(0, d.rootRef)) return RT_ERR_SCENE;
+        if (d.identifiersCount >= 65536) commitLap("uploaded tree", mark);
         descs[(size_t)m] = d;
     }
     return RT_OK;
@@ -385,7 +430,7 @@ void packTextures(const rt_scene_host *ctx, bool enable, TexturePack &out) {
 // triangles in leaf order.  Boxes are the exact bounds of the vertices; the
 // margin the device arithmetic needs is added when they are quantised.
 template <typename Emit>
-bool sahTree(const std::vector<float> &mdl, const ModelDesc &d, const std::vector<PackedTri> &tris, std::vector<PackedTri> &wtris, Emit emit) {
+bool sahTree(const std::vector<float> &mdl, const ModelDesc &d, const PackedTris &tris, PackedTris &wtris, Emit emit) {
     const int T = d.identifiersCount;
     auto mark = std::chrono::steady_clock::now();
     struct Prim { float box[6]; float centre[3]; };
@@ -646,7 +691,7 @@ struct BinaryTrees {
 // Fills `trees` with every model's binary tree: the library's own binned-SAH tree when `rebuild` (then
 // `wtris` receives the triangle records in that tree's leaf order), else the uploaded one.  A model
 // whose tree is a single leaf gets that leaf's reference in wideRootRef and no entry in `roots`.
-int binaryTreesOfModels(rt_scene_host *ctx, std::vector<ModelDesc> &descs, const std::vector<PackedTri> &tris, std::vector<PackedTri> &wtris, bool rebuild, BinaryTrees &trees) {
+int binaryTreesOfModels(rt_scene_host *ctx, std::vector<ModelDesc> &descs, const PackedTris &tris, PackedTris &wtris, bool rebuild, BinaryTrees &trees) {
     const std::vector<float> &mdl = ctx->host[RT_SLOT_MODELS];
     std::vector<BinNode> &bin = trees.bin;
     auto &roots = trees.roots;
@@ -756,7 +801,7 @@ int binaryTreesOfModels(rt_scene_host *ctx, std::vector<ModelDesc> &descs, const
 // Four-wide tree of every model, collapsed from the binary tree of the model stream: a node adopts
 // the children of its child with the largest box until it has four (or only leaves are left).
 // `descs` must have passed repackScene; wideRootRef receives the new tree's root.
-int buildWideNodes(rt_scene_host *ctx, std::vector<ModelDesc> &descs, std::vector<WideNode> &wnodes, const std::vector<PackedTri> &tris, std::vector<PackedTri> &wtris) {
+int buildWideNodes(rt_scene_host *ctx, std::vector<ModelDesc> &descs, std::vector<WideNode> &wnodes, const PackedTris &tris, PackedTris &wtris) {
     ctx->wideStackNeed = 0;
     BinaryTrees trees;
     const int treesRc = binaryTreesOfModels(ctx, descs, tris, wtris, ctx->wideBvh >= 2, trees);
@@ -987,7 +1032,7 @@ int buildWideNodes(rt_scene_host *ctx, std::vector<ModelDesc> &descs, std::vecto
 
 // Re-packs the leaves of the four-wide trees as triangle pairs (TriPair) and rewrites every leaf
 // reference, in the nodes and in the models' roots, from (first triangle, triangles) to (first pair, pairs).
-void pairLeaves(std::vector<WideNode> &wnodes, std::vector<ModelDesc> &descs, const std::vector<PackedTri> &wtris, std::vector<TriPair> &wpairs) {
+void pairLeaves(std::vector<WideNode> &wnodes, std::vector<ModelDesc> &descs, const PackedTris &wtris, std::vector<TriPair> &wpairs) {
     wpairs.clear();
     wpairs.reserve(wtris.size() * 2 / 3 + 1);
     auto paired = [&](int32_t ref) -> int32_t {
@@ -1022,10 +1067,10 @@ void pairLeaves(std::vector<WideNode> &wnodes, std::vector<ModelDesc> &descs, co
 // the triangles of its leaf children consecutive places in `w8tris`, both in slot order; slots are
 // dealt so that a child lying towards (+x, +y, +z) of the node's centre sits in the slot whose number
 // has those bits set, which lets the device visit children front to back by slot number alone.
-int buildWide8(rt_scene_host *ctx, std::vector<ModelDesc> &descs, std::vector<Wide8Node> &w8, const std::vector<PackedTri> &tris, std::vector<PackedTri> &w8tris) {
+int buildWide8(rt_scene_host *ctx, std::vector<ModelDesc> &descs, std::vector<Wide8Node> &w8, const PackedTris &tris, PackedTris &w8tris) {
     ctx->wideStackNeed = 0;
     BinaryTrees trees;
-    std::vector<PackedTri> leafTris;   // in the binary trees' leaf order
+    PackedTris leafTris;   // in the binary trees' leaf order
     const int treesRc = binaryTreesOfModels(ctx, descs, tris, leafTris, true, trees);
     if (treesRc != RT_OK) return treesRc;
     const std::vector<BinNode> &bin = trees.bin;

@@ -3,12 +3,31 @@
 #pragma once
 
 #include <cstdint>
+#include <cstdlib>
+#include <memory>
+#include <utility>
 #include <vector>
 
 #include "rt_hip.h"      // status codes, slot numbers
 #include "rt_device.h"   // record layouts shared with the kernels
 
 namespace rtc {
+// Arrays of the re-packed records: their elements are written by the threads that fill them, so growing one does
+// not clear the new elements first (a cleared half-gigabyte is a pass over memory by one thread).
+// Large arrays start on a 2 MiB boundary and ask for huge pages: first touch of fresh memory by 4 KiB pages is
+// page-fault bound, whatever the number of threads.
+void *allocateRecords(size_t bytes);
+template <typename T> struct Uncleared : std::allocator<T> {
+    template <typename U> struct rebind { using other = Uncleared<U>; };
+    T *allocate(size_t n) { return static_cast<T *>(allocateRecords(n * sizeof(T))); }
+    void deallocate(T *p, size_t) noexcept { std::free(p); }
+    template <typename U> void construct(U *p) { ::new (static_cast<void *>(p)) U; }
+    template <typename U, typename A, typename... More> void construct(U *p, A &&a, More &&...more) { ::new (static_cast<void *>(p)) U(std::forward<A>(a), std::forward<More>(more)...); }
+};
+using PackedTris = std::vector<rtd::PackedTri, Uncleared<rtd::PackedTri>>;
+using PackedShades = std::vector<rtd::PackedShade, Uncleared<rtd::PackedShade>>;
+using PackedUVs = std::vector<rtd::PackedUV, Uncleared<rtd::PackedUV>>;
+using PackedNodes = std::vector<rtd::PackedNode, Uncleared<rtd::PackedNode>>;
 // A node of a model's binary tree as the collapse into wide nodes reads it: box, children (node numbers), or the
 // leaf reference ~((first triangle << 2) | triangle count).
 struct BinNode { float box[6]; int32_t left, right; int32_t leafRef; bool leaf; };
@@ -61,15 +80,15 @@ void colourTables8(float table[512]);
 
 // Builds the traversal re-pack from the uploaded model streams and validates every offset the
 // kernels will follow.  RT_ERR_SCENE for a stream the kernels could not walk safely.
-int repackScene(rt_scene_host *ctx, std::vector<rtd::PackedNode> &nodes, std::vector<rtd::PackedTri> &tris, std::vector<rtd::PackedShade> &shade,
-                std::vector<rtd::PackedUV> &uvs, std::vector<rtd::LightTri> &lightTris, std::vector<rtd::ModelDesc> &descs);
+int repackScene(rt_scene_host *ctx, PackedNodes &nodes, PackedTris &tris, PackedShades &shade,
+                PackedUVs &uvs, std::vector<rtd::LightTri> &lightTris, std::vector<rtd::ModelDesc> &descs);
 // Four-wide trees of every model (ctx->wideBvh 1: collapsed from the uploaded trees; >= 2: from the library's own).
-int buildWideNodes(rt_scene_host *ctx, std::vector<rtd::ModelDesc> &descs, std::vector<rtd::WideNode> &wnodes, const std::vector<rtd::PackedTri> &tris,
-                   std::vector<rtd::PackedTri> &wtris);
+int buildWideNodes(rt_scene_host *ctx, std::vector<rtd::ModelDesc> &descs, std::vector<rtd::WideNode> &wnodes, const PackedTris &tris,
+                   PackedTris &wtris);
 // Re-packs the leaves of four-wide trees as triangle pairs; leaf references then count pairs.
-void pairLeaves(std::vector<rtd::WideNode> &wnodes, std::vector<rtd::ModelDesc> &descs, const std::vector<rtd::PackedTri> &wtris, std::vector<rtd::TriPair> &wpairs);
+void pairLeaves(std::vector<rtd::WideNode> &wnodes, std::vector<rtd::ModelDesc> &descs, const PackedTris &wtris, std::vector<rtd::TriPair> &wpairs);
 // Eight-wide trees over the library's own binary trees.
-int buildWide8(rt_scene_host *ctx, std::vector<rtd::ModelDesc> &descs, std::vector<rtd::Wide8Node> &w8, const std::vector<rtd::PackedTri> &tris,
-               std::vector<rtd::PackedTri> &w8tris);
+int buildWide8(rt_scene_host *ctx, std::vector<rtd::ModelDesc> &descs, std::vector<rtd::Wide8Node> &w8, const PackedTris &tris,
+               PackedTris &w8tris);
 
 }  // namespace rtc

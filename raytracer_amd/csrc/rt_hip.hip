@@ -94,7 +94,7 @@ struct rt_ctx : rt_scene_host {
     LightTri *dLightTris = nullptr;
     int32_t *dPrimAt = nullptr;     // word offset of every analytic primitive's record in the objects stream
     ModelDesc *dModelDesc = nullptr;
-    std::vector<PackedTri> hTris;   // kept for id decoding in rt_trace_primary
+    rtc::PackedTris hTris;   // kept for id decoding in rt_trace_primary
     SceneView view{};
 
     int W = 0, H = 0;
@@ -673,10 +673,10 @@ static int commitScene(rt_ctx *ctx, int objectCount, int modelsCount, int lightS
     ctx->modelsCount = modelsCount;
     ctx->lightSourcesCount = lightSourcesCount;
 
-    std::vector<PackedNode> nodes;
-    std::vector<PackedTri> tris;
-    std::vector<PackedShade> shade;
-    std::vector<PackedUV> uvs;
+    rtc::PackedNodes nodes;
+    rtc::PackedTris tris;
+    rtc::PackedShades shade;
+    rtc::PackedUVs uvs;
     std::vector<LightTri> lightTris;
     std::vector<ModelDesc> descs;
     // RT_COMMIT_TIMING=1 prints where a commit spends its host time.
@@ -714,7 +714,7 @@ static int commitScene(rt_ctx *ctx, int objectCount, int modelsCount, int lightS
     lap("stream upload", mark);
     std::vector<WideNode> wnodes;
     std::vector<Wide8Node> w8nodes;
-    std::vector<PackedTri> wtris;
+    rtc::PackedTris wtris;
     ctx->wideNow = tris.empty() ? 0 : ctx->wideBvh;   // nothing to build over analytic primitives alone
     // The eight-wide kernel has no alpha-cut phase: scenes with alpha-cut textures walk the four-wide trees.
     if (ctx->wideNow == 4 && ctx->hasAlphaTest) ctx->wideNow = 3;

@@ -50,10 +50,10 @@ struct Rng {
 // The commit as rt_commit_scene runs it, for one tree mode.  Returns its status.
 int commitOnce(rt_ctx *ctx, int mode) {
     using namespace rtd;
-    std::vector<PackedNode> nodes;
-    std::vector<PackedTri> tris, wtris;
-    std::vector<PackedShade> shade;
-    std::vector<PackedUV> uvs;
+    rtc::PackedNodes nodes;
+    rtc::PackedTris tris, wtris;
+    rtc::PackedShades shade;
+    rtc::PackedUVs uvs;
     std::vector<LightTri> lightTris;
     std::vector<ModelDesc> descs;
     int rc = rtc::repackScene(ctx, nodes, tris, shade, uvs, lightTris, descs);
@@ -78,10 +78,10 @@ uint64_t hashBytes(const void *p, size_t n, uint64_t h = 1469598103934665603ull)
 // Hash of the four-wide trees the library builds for the context's streams.
 uint64_t wideTreeHash(rt_ctx *ctx) {
     using namespace rtd;
-    std::vector<PackedNode> nodes;
-    std::vector<PackedTri> tris, wtris;
-    std::vector<PackedShade> shade;
-    std::vector<PackedUV> uvs;
+    rtc::PackedNodes nodes;
+    rtc::PackedTris tris, wtris;
+    rtc::PackedShades shade;
+    rtc::PackedUVs uvs;
     std::vector<LightTri> lightTris;
     std::vector<ModelDesc> descs;
     if (rtc::repackScene(ctx, nodes, tris, shade, uvs, lightTris, descs) != RT_OK) return 0;
