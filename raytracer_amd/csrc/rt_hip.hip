@@ -723,7 +723,8 @@ static int commitScene(rt_ctx *ctx, int objectCount, int modelsCount, int lightS
     if (!tris.empty()) RT_HIP(hipMemcpy(ctx->dTris, tris.data(), tris.size() * sizeof(PackedTri), hipMemcpyHostToDevice));
     // Four-wide trees and their leaves made on the device from the uploaded streams (the eight-wide trees take the
     // device's binary trees through the host's collapse).
-    const bool wideOnDevice = ctx->treeOnDevice && (ctx->wideNow == 2 || ctx->wideNow == 3);
+    // (leaves as triangles take two records per leaf: their index must stay within the 29 bits of a leaf reference)
+    const bool wideOnDevice = ctx->treeOnDevice && (ctx->wideNow == 2 || ctx->wideNow == 3) && (!ctx->hasAlphaTest || tris.size() < (1u << 27));
     rttree::WideTrees deviceWide;
     if (wideOnDevice) {
         std::vector<rttree::ModelTriangles> models;

@@ -29,6 +29,9 @@ SCENES = [
     ("empty", {}),
     ("textured_room", dict(nu=64, nv=16, tex_size=32)),
     ("interior", dict(nu=48, nv=12, tex_size=32)),
+    ("fuzz", dict(nu=1, nv=2, seed=3)),                    # models of one and three triangles
+    ("fuzz", dict(nu=2, nv=2, seed=4)),                    # of two and four
+    ("panel_floor", {}),                                   # one model that is a single leaf of two triangles
 ]
 
 
