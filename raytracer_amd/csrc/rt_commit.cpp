@@ -830,7 +830,6 @@ int buildWideNodes(rt_scene_host *ctx, std::vector<ModelDesc> &descs, std::vecto
     // keeps the earlier rule: a node adopts the children of its child with the largest box until it has four.
     // (Every leaf is visited through exactly one slot whatever the cut, so the leaves' share of the cost is the same
     // for all cuts: only the areas of the nodes that become wide nodes decide.  Measured: any leaf weight, same trees.)
-    constexpr double kNodeCost = kWideNodeCost, kLeafCost = kWideLeafCost;
     static const bool greedyCollapse = std::getenv("RT_COLLAPSE") != nullptr && std::strcmp(std::getenv("RT_COLLAPSE"), "greedy") == 0;
     struct Cut { float cost[3]; uint8_t split[5]; };   // split[j], j = 2..4: slots given to the left child when j are shared out; 0 = use j - 1
     std::vector<Cut> cuts;
@@ -845,8 +844,7 @@ int buildWideNodes(rt_scene_host *ctx, std::vector<ModelDesc> &descs, std::vecto
             const BinNode &b = bin[(size_t)n];
             Cut &c = cuts[(size_t)n];
             if (b.leaf) {
-                const float leafCost = leafCount(n) == 0 ? 0.0f : (float)(area(n) * kLeafCost);
-                c.cost[0] = c.cost[1] = c.cost[2] = leafCost;
+                leafCutCost(b.box, leafCount(n) == 0, c.cost);
                 continue;
             }
             if (!done) {
@@ -856,23 +854,7 @@ int buildWideNodes(rt_scene_host *ctx, std::vector<ModelDesc> &descs, std::vecto
                 continue;
             }
             const Cut &l = cuts[(size_t)b.left], &r = cuts[(size_t)b.right];
-            double share[5] = {0, 0, 0, 0, 0};   // share[j]: cheapest way to stand for both children with j slots
-            for (int j = 2; j <= 4; ++j) {
-                double best = 0.0;
-                int bestK = 0;
-                for (int k = 1; k < j; ++k) {
-                    if (k > 3 || j - k > 3) continue;
-                    const double v = (double)l.cost[k - 1] + (double)r.cost[j - k - 1];
-                    if (bestK == 0 || v < best) { best = v; bestK = k; }
-                }
-                share[j] = best;
-                c.split[j] = (uint8_t)bestK;
-            }
-            c.cost[0] = (float)(area(n) * kNodeCost + share[4]);          // one slot: a wide node of its own
-            for (int i = 1; i < 3; ++i) {
-                if ((float)share[i + 1] < c.cost[i - 1]) c.cost[i] = (float)share[i + 1];
-                else { c.cost[i] = c.cost[i - 1]; c.split[i + 1] = c.split[i + 1] | 0x80; }   // marked: fewer slots are as cheap
-            }
+            innerCutCost(b.box, l.cost, r.cost, c.cost, c.split);
         }
         };
         ThreadGroup pool(roots.size());

@@ -34,6 +34,40 @@ struct BinNode { float box[6]; int32_t left, right; int32_t leafRef; bool leaf; 
 // What a visit of a wide node / of a leaf costs, per unit of its surface, when the collapse chooses which binary
 // nodes become the children of a wide node (buildWideNodes; the device build uses the same figures).
 constexpr double kWideNodeCost = 1.0, kWideLeafCost = 0.9;
+
+// The cheapest way to stand for a binary subtree with 1, 2 or 3 slots of a four-wide parent (cost[0..2]) and how
+// the slots are shared out between its two children (split[j], j = 2..4: slots given to the left child when j
+// are shared out; bit 7 marks "one slot fewer is as cheap").  Solved bottom-up: a leaf costs its surface x
+// kWideLeafCost whatever the slots; an inner node with one slot becomes a wide node of its own (its surface x
+// kWideNodeCost plus the cheapest way to stand for both children with four slots), with more slots it may hand
+// them to its children instead.  Shared by the host collapse and the device build.
+RT_FN double boxHalfArea(const float *b) {
+    const double ex = (double)b[3] - b[0], ey = (double)b[4] - b[1], ez = (double)b[5] - b[2];
+    return ex * ey + ey * ez + ez * ex;
+}
+RT_FN void leafCutCost(const float *box, bool empty, float cost[3]) {
+    cost[0] = cost[1] = cost[2] = empty ? 0.0f : (float)(boxHalfArea(box) * kWideLeafCost);
+}
+RT_FN void innerCutCost(const float *box, const float lcost[3], const float rcost[3], float cost[3], uint8_t split[5]) {
+    double share[5] = {0, 0, 0, 0, 0};
+    split[0] = split[1] = 0;
+    for (int j = 2; j <= 4; ++j) {
+        double best = 0.0;
+        int bestK = 0;
+        for (int k = 1; k < j; ++k) {
+            if (k > 3 || j - k > 3) continue;
+            const double v = (double)lcost[k - 1] + (double)rcost[j - k - 1];
+            if (bestK == 0 || v < best) { best = v; bestK = k; }
+        }
+        share[j] = best;
+        split[j] = (uint8_t)bestK;
+    }
+    cost[0] = (float)(boxHalfArea(box) * kWideNodeCost + share[4]);
+    for (int i = 1; i < 3; ++i) {
+        if ((float)share[i + 1] < cost[i - 1]) cost[i] = (float)share[i + 1];
+        else { cost[i] = cost[i - 1]; split[i + 1] = (uint8_t)(split[i + 1] | 0x80); }
+    }
+}
 }  // namespace rtc
 
 // The part of a context the commit-time code reads and writes; rt_ctx derives from it.

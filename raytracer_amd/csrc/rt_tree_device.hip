@@ -131,33 +131,13 @@ struct BuildNode {
     uint8_t split[8];
 };
 
-__device__ __forceinline__ double halfArea(const float *b) {
-    const double ex = (double)b[3] - b[0], ey = (double)b[4] - b[1], ez = (double)b[5] - b[2];
-    return ex * ey + ey * ez + ez * ex;
-}
 __device__ __forceinline__ void leafCut(BuildNode &n) {
-    n.cost[0] = n.cost[1] = n.cost[2] = (float)(halfArea(n.box) * rtc::kWideLeafCost);
+    rtc::leafCutCost(n.box, false, n.cost);
     for (int k = 0; k < 8; ++k) n.split[k] = 0;
 }
 __device__ __forceinline__ void innerCut(BuildNode &n, const BuildNode &l, const BuildNode &r) {
-    double share[5] = {0, 0, 0, 0, 0};
     for (int k = 0; k < 8; ++k) n.split[k] = 0;
-    for (int j = 2; j <= 4; ++j) {
-        double best = 0.0;
-        int bestK = 0;
-        for (int k = 1; k < j; ++k) {
-            if (k > 3 || j - k > 3) continue;
-            const double v = (double)l.cost[k - 1] + (double)r.cost[j - k - 1];
-            if (bestK == 0 || v < best) { best = v; bestK = k; }
-        }
-        share[j] = best;
-        n.split[j] = (uint8_t)bestK;
-    }
-    n.cost[0] = (float)(halfArea(n.box) * rtc::kWideNodeCost + share[4]);
-    for (int i = 1; i < 3; ++i) {
-        if ((float)share[i + 1] < n.cost[i - 1]) n.cost[i] = (float)share[i + 1];
-        else { n.cost[i] = n.cost[i - 1]; n.split[i + 1] = n.split[i + 1] | 0x80; }
-    }
+    rtc::innerCutCost(n.box, l.cost, r.cost, n.cost, n.split);
 }
 
 __device__ __forceinline__ float unionHalfArea(const float *a, const float *b) {
