@@ -126,3 +126,53 @@ def test_device_tree_declines_what_the_host_build_declines(value, where):
             assert np.array_equal(got, want, equal_nan=True)
     finally:
         b.close()
+
+
+def test_device_tree_is_the_same_tree_every_time():
+    """Node numbers come from prefix sums, not from atomics: two commits give the same tree, hence the same
+    visit counts (and the counts differ from the host trees', so the option did take effect)."""
+    scene = capi.Scene("cornell_knot", nu=512, nv=80)
+    cam = capi.make_camera(width=96, height=64, bounces=3, ray_per_pixel=1)
+    seen = []
+    for where in (capi.RT_TREE_BUILD_DEVICE, capi.RT_TREE_BUILD_DEVICE, capi.RT_TREE_BUILD_HOST):
+        b = capi.Backend(0)
+        try:
+            b.set_option(capi.RT_OPT_TREE_BUILD, where)
+            b.upload_scene(scene)
+            b.resize(96, 64)
+            b.set_frame(cam, scene.sky, capi.RT_TYPE_RGB)
+            b.set_counters(True)
+            b.reset_stats()
+            b.render(1, 2, 1)
+            st = b.stats()
+            img, _ = b.readback()
+            seen.append((st["node_visits"], st["tri_tests"], st["max_stack"], img))
+        finally:
+            b.close()
+    assert seen[0][:3] == seen[1][:3]
+    assert seen[0][:2] != seen[2][:2]
+    assert np.array_equal(seen[0][3], seen[1][3]) and np.array_equal(seen[0][3], seen[2][3])
+
+
+def test_tree_options_may_be_flipped_on_a_committed_scene():
+    """Every pair (who builds, which trees) on one context, one after the other: same image each time."""
+    scene = capi.Scene("mixed", nu=96, nv=16)
+    cam = capi.make_camera(width=64, height=48, bounces=4, ray_per_pixel=2)
+    want, _ = OracleScene(scene).render(cam, capi.RT_TYPE_RGB, 1, 2, 1)
+    b = capi.Backend(0)
+    try:
+        b.upload_scene(scene)
+        b.resize(64, 48)
+        for where in (capi.RT_TREE_BUILD_DEVICE, capi.RT_TREE_BUILD_HOST, capi.RT_TREE_BUILD_DEVICE):
+            b.set_option(capi.RT_OPT_TREE_BUILD, where)
+            for mode in (3, 0, 4, 2, 1, 3):
+                b.set_option(capi.RT_OPT_WIDE_BVH, mode)
+                assert b.info(capi.RT_INFO_TREE_MODE) == mode
+                b.set_frame(cam, scene.sky, capi.RT_TYPE_RGB)
+                b.reset_accum()
+                b.render(1, 2, 1)
+                got, _ = b.readback()
+                if mode in (0, 3, 4):   # (1 and 2 may let the other triangle of a distance tie win)
+                    assert np.array_equal(got, want, equal_nan=True), f"where {where} mode {mode}"
+    finally:
+        b.close()
