@@ -733,6 +733,10 @@ int binaryTreesOfModels(rt_scene_host *ctx, std::vector<ModelDesc> &descs, const
             for (size_t m : jobs) {
                 const ModelDesc &d = descs[m];
                 const int rc = ctx->deviceTree(ctx, d, own[m], order);
+                if (rc == RT_ERR_NOMEM) {   // no room on the device for the build's scratch: this model and the rest on the host
+                    own[m].clear();
+                    break;
+                }
                 if (rc != RT_OK) return rc;
                 if (order.size() != (size_t)d.identifiersCount) return RT_ERR_SCENE;
                 for (int i = 0; i < d.identifiersCount; ++i) {
@@ -742,7 +746,7 @@ int binaryTreesOfModels(rt_scene_host *ctx, std::vector<ModelDesc> &descs, const
                     wtris[(size_t)d.triBase + (size_t)i] = pt;
                 }
             }
-            jobs.clear();
+            jobs.erase(std::remove_if(jobs.begin(), jobs.end(), [&](size_t m) { return !own[m].empty(); }), jobs.end());
             commitLap("binary trees on the device", mark);
         }
         ThreadGroup pool(jobs.size());

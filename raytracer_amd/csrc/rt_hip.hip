@@ -724,23 +724,31 @@ static int commitScene(rt_ctx *ctx, int objectCount, int modelsCount, int lightS
     // Four-wide trees and their leaves made on the device from the uploaded streams (the eight-wide trees take the
     // device's binary trees through the host's collapse).
     // (leaves as triangles take two records per leaf: their index must stay within the 29 bits of a leaf reference)
-    const bool wideOnDevice = ctx->treeOnDevice && (ctx->wideNow == 2 || ctx->wideNow == 3) && (!ctx->hasAlphaTest || tris.size() < (1u << 27));
+    bool wideOnDevice = ctx->treeOnDevice && (ctx->wideNow == 2 || ctx->wideNow == 3) && (!ctx->hasAlphaTest || tris.size() < (1u << 27));
     rttree::WideTrees deviceWide;
     if (wideOnDevice) {
         std::vector<rttree::ModelTriangles> models;
         for (const ModelDesc &d : descs)
             models.push_back({ctx->dStream[RT_SLOT_MODELS], d.identBase, d.vertBase, (d.nodesCount > 0 && d.identifiersCount > 0) ? d.identifiersCount : 0, d.triBase});
         rc = rttree::buildWideTrees(ctx->stream, models, ctx->dTris, ctx->hasAlphaTest, deviceWide, ctx->hipError);
-        if (rc == RT_ERR_SCENE && !ctx->wideChosen) ctx->wideNow = 0;
-        else if (rc != RT_OK) return rc;
-        if (rc == RT_OK) {
+        if (rc == RT_ERR_NOMEM) {
+            // No room on the device for the build's scratch (a few hundred bytes per triangle): the host builds.
+            (void)hipGetLastError();
+            wideOnDevice = false;
+            ctx->deviceTree = nullptr;
+        } else if (rc == RT_ERR_SCENE && !ctx->wideChosen) {
+            ctx->wideNow = 0;
+        } else if (rc != RT_OK) {
+            return rc;
+        } else {
             for (size_t m = 0; m < descs.size(); ++m) {
                 ModelDesc &d = descs[m];
                 d.wideRootRef = models[m].count > 0 ? deviceWide.rootRefs[m] : d.rootRef;   // (no triangles: as the host build leaves it)
             }
             ctx->wideStackNeed = deviceWide.stackNeed;
         }
-    } else if (ctx->wideNow) {
+    }
+    if (!wideOnDevice && ctx->wideNow) {
         rc = ctx->wideNow == 4 ? buildWide8(ctx, descs, w8nodes, tris, wtris) : buildWideNodes(ctx, descs, wnodes, tris, wtris);
         // A scene the wide build cannot take (coordinates beyond its box arithmetic, NaN) is
         // walked in the reference's order, as it would be with the option off, unless the caller

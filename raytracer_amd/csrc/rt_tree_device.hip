@@ -159,24 +159,35 @@ __global__ __launch_bounds__(kThreads) void k_first_clusters(int count, const fl
     cluster[p] = p;
 }
 
-// nearest[i] = the place within kRadius of i whose union with cluster i has the least surface; equal surfaces are
-// told apart by the pair of places, the same way from both sides, so the best pair of all always chooses each other.
-__global__ __launch_bounds__(kThreads) void k_nearest(int clusters, int radius, const float *clusterBox, int32_t *nearest) {
+// nearest[i] = the place within `radius` of i whose union with cluster i has the least surface.  Equal surfaces are
+// told apart by the pair of places (lo, hi), the same way from both sides, so the best pair of all always chooses
+// each other and every round merges something; the order among equals -- pairs that start at an even place first,
+// then the closer ones -- makes a run of identical boxes pair up (0,1), (2,3), ... at once instead of one pair per
+// round.  With `forced` every cluster simply takes its neighbour of that pairing: the host asks for it after a round
+// that merged next to nothing (surfaces that grow steadily along the order chain every choice to the previous place).
+__global__ __launch_bounds__(kThreads) void k_nearest(int clusters, int radius, int forced, const float *clusterBox, int32_t *nearest) {
     const int i = (int)(blockIdx.x * kThreads + threadIdx.x);
     if (i >= clusters) return;
+    if (forced) {
+        const int j = i ^ 1;
+        nearest[i] = j < clusters ? j : -1;
+        return;
+    }
     float mine[6];
     for (int a = 0; a < 6; ++a) mine[a] = clusterBox[(size_t)i * 6 + a];
     const int from = i - radius < 0 ? 0 : i - radius, to = i + radius >= clusters ? clusters - 1 : i + radius;
     float best = INFINITY;
-    int bestLo = 0x7fffffff, bestHi = 0x7fffffff, at = -1;
+    int bestOdd = 2, bestGap = 0x7fffffff, bestLo = 0x7fffffff, at = -1;
     for (int j = from; j <= to; ++j) {
         if (j == i) continue;
         const float area = unionHalfArea(mine, clusterBox + (size_t)j * 6);
-        const int lo = i < j ? i : j, hi = i < j ? j : i;
-        if (at < 0 || area < best || (area == best && (lo < bestLo || (lo == bestLo && hi < bestHi)))) {
+        const int lo = i < j ? i : j, gap = i < j ? j - i : i - j, odd = lo & 1;
+        const bool better = at < 0 || area < best || (area == best && (odd < bestOdd || (odd == bestOdd && (gap < bestGap || (gap == bestGap && lo < bestLo)))));
+        if (better) {
             best = area;
+            bestOdd = odd;
+            bestGap = gap;
             bestLo = lo;
-            bestHi = hi;
             at = j;
         }
     }
@@ -559,10 +570,11 @@ int clusterModel(hipStream_t stream, const ModelTriangles &model, ModelBuild &mb
     hipLaunchKernelGGL(k_first_clusters, blocksFor(count), dim3(kThreads), 0, stream, count, boxes, mb.sorted, mb.build, cluster[0], clusterBox[0]);
     int radius = kRadius;
     if (const char *env = std::getenv("RT_TREE_RADIUS")) radius = std::min(std::max(std::atoi(env), 1), 256);   // (for measurements)
-    int clusters = count, made = 0, side = 0, rounds = 0;
+    static const bool alwaysForced = std::getenv("RT_TREE_FORCE_PAIRS") != nullptr;   // (a testing aid: every round pairs neighbours)
+    int clusters = count, made = 0, side = 0, rounds = 0, forced = alwaysForced ? 1 : 0;
     while (clusters > 1) {
         ++rounds;
-        hipLaunchKernelGGL(k_nearest, blocksFor(clusters), dim3(kThreads), 0, stream, clusters, radius, clusterBox[side], nearest);
+        hipLaunchKernelGGL(k_nearest, blocksFor(clusters), dim3(kThreads), 0, stream, clusters, radius, forced, clusterBox[side], nearest);
         hipLaunchKernelGGL(k_mark_pairs, blocksFor(clusters), dim3(kThreads), 0, stream, clusters, nearest, mb.flags);
         RT_TREE_HIP(hipcub::DeviceScan::ExclusiveSum(mb.scratch, mb.scanBytes, mb.flags, mb.sums, clusters, stream));
         hipLaunchKernelGGL(k_merge, blocksFor(clusters), dim3(kThreads), 0, stream, clusters, count, count + made, nearest, mb.flags, mb.sums, cluster[side], clusterBox[side],
@@ -571,6 +583,9 @@ int clusterModel(hipStream_t stream, const ModelTriangles &model, ModelBuild &mb
         RT_TREE_HIP(hipMemcpyAsync(totals, mb.header + 8, sizeof totals, hipMemcpyDeviceToHost, stream));
         RT_TREE_HIP(hipStreamSynchronize(stream));
         if (totals[1] == 0u || (int)totals[0] != clusters - (int)totals[1]) { error = "tree build: a clustering round merged nothing"; return RT_ERR_HIP; }
+        // A round that merged less than a sixteenth of its clusters is followed by one that pairs neighbours whatever
+        // their surfaces, so the number of rounds stays logarithmic on any input.
+        forced = (alwaysForced || (int)totals[1] * 16 < clusters) ? 1 : 0;
         clusters = (int)totals[0];
         made += (int)totals[1];
         side ^= 1;

@@ -176,3 +176,62 @@ def test_tree_options_may_be_flipped_on_a_committed_scene():
                     assert np.array_equal(got, want, equal_nan=True), f"where {where} mode {mode}"
     finally:
         b.close()
+
+
+def _glb_of_triangles(path, positions):
+    """One mesh of len(positions) / 3 triangles (positions (n, 3), three rows per triangle)."""
+    from glb_writer import GlbBuilder, U32
+    b = GlbBuilder()
+    grey = b.material(pbrMetallicRoughness={"baseColorFactor": [0.7, 0.7, 0.7, 1], "metallicFactor": 0.0})
+    positions = np.asarray(positions, np.float32)
+    normals = np.tile(np.array([[0, 1, 0]], np.float32), (len(positions), 1))
+    mesh = b.mesh([b.primitive(positions, np.arange(len(positions), dtype=np.uint32), grey, normals=normals, index_type=U32)])
+    b.node(mesh=mesh, root=True)
+    return b.write(path)
+
+
+@pytest.mark.parametrize("kind", ["identical", "growing"])
+def test_device_tree_rounds_stay_few_on_degenerate_models(tmp_path, kind):
+    """120,000 copies of one triangle (every surface equal: the order among equals must pair them up at once) and
+    120,000 triangles whose boxes grow steadily along the sorted order (every cluster prefers its smaller neighbour:
+    the forced pairing after a round that merged next to nothing) -- either would take one round per triangle
+    otherwise, seconds of launches.  Commit only: tracing 120,000 coincident triangles is no test of the build."""
+    import time
+    n = 120000
+    if kind == "identical":
+        tri = np.array([[0, 0, 0], [1, 0, 0], [0, 0, 1]], np.float32)
+        positions = np.tile(tri, (n, 1))
+    else:
+        k = np.arange(n, dtype=np.float64)
+        size = 1e-6 * 1.0001 ** k                 # box k reaches from the origin to size[k]: a chain of nested boxes
+        positions = np.zeros((n, 3, 3), np.float64)
+        positions[:, 1, 0] = size
+        positions[:, 2, 2] = size
+        positions[:, :, 1] = (k * 1e-9)[:, None]
+        positions = positions.reshape(-1, 3)
+    scene = capi.Scene("glb:" + str(_glb_of_triangles(tmp_path / f"{kind}.glb", positions)))
+    b = capi.Backend(0)
+    try:
+        b.set_option(capi.RT_OPT_TREE_BUILD, capi.RT_TREE_BUILD_DEVICE)
+        b.set_option(capi.RT_OPT_WIDE_BVH, 3)
+        t0 = time.perf_counter()
+        b.upload_scene(scene)
+        took = time.perf_counter() - t0
+        assert b.info(capi.RT_INFO_TREE_MODE) == 3
+        assert took < 1.0, f"commit took {took:.2f} s"
+    finally:
+        b.close()
+
+
+def test_device_tree_with_every_round_forced(monkeypatch):
+    """The fallback pairing alone (neighbours of the sorted order merged whatever their surfaces) still gives a valid tree."""
+    monkeypatch.setenv("RT_TREE_FORCE_PAIRS", "1")
+    import subprocess, sys, os
+    code = ("import numpy as np, sys; sys.path[:0] = ['.', 'tests'];"
+            "from raytracer_amd import capi; from oracle_binding import OracleScene;"
+            "s = capi.Scene('cornell_knot', nu=96, nv=16); c = capi.make_camera(width=48, height=36, bounces=3, ray_per_pixel=2);"
+            "b = capi.Backend(0); b.set_option(capi.RT_OPT_TREE_BUILD, 1); b.upload_scene(s); b.resize(48, 36);"
+            "b.set_frame(c, s.sky, capi.RT_TYPE_RGB); b.render(1, 2, 1); g, _ = b.readback(); b.close();"
+            "w, _ = OracleScene(s).render(c, capi.RT_TYPE_RGB, 1, 2, 1); sys.exit(0 if np.array_equal(g, w, equal_nan=True) else 3)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    assert subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ)).returncode == 0
