@@ -1,4 +1,4 @@
-# The round's measurement set on one box: bash tools/r03_measure.sh TAG  (outputs under gpurun_out/)
+# The measurement set on one box: bash tools/measure_set.sh TAG  (outputs under gpurun_out/)
 set -e
 TAG=$1
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
