@@ -35,14 +35,7 @@ __global__ __launch_bounds__(kBlock) void k_generate(FrameParams fp, Batch bt, P
         float4 first = make_float4(1.0f, 1.0f, 0.0f, 0.0f);   // Spectral: the path's initial stA (throughput, previous pdf, wavelength)
         if (p < total) {
             uint32_t k, q;
-            if (bt.planesInner) {
-                const uint32_t w = p >> 6;
-                k = w % bt.K;
-                q = ((w / bt.K) << 6) | (p & 63u);
-            } else {
-                k = p / fp.npt;
-                q = p - k * fp.npt;
-            }
+            pathOf(fp, bt, p, k, q);
             int x, y;
             valid = pathPixel(fp, q, x, y);
             if (valid) {

@@ -68,10 +68,13 @@ struct Batch {
     uint32_t firstFrame, frameStride;
     uint32_t P;          // capacity in paths; shadow-ray slots start at P
     uint32_t planesInner;   // path order: 1 = tile-major (all K samples of a tile adjacent), 0 = plane-major
+    uint32_t waveSamples;   // tile-major only: samples per wave (1, 4, 16 or 64; divides K): a wave holds that many samples of 64 / waveSamples pixels
 };
 
 // Path index of sample plane k (0..K-1) of padded pixel q.  Tile-major order keeps the rays in
-// flight at any moment inside a small screen region, so they share the tree nodes they open.
+// flight at any moment inside a small screen region, so they share the tree nodes they open; with several samples
+// per wave a wave's camera rays cover a 2x2-pixel block instead of 8x8 pixels, and so do the surface points its
+// paths go on from.
 __device__ __forceinline__ uint32_t pathIndex(const FrameParams &fp, const Batch &bt, uint32_t k, uint32_t q);
 
 
@@ -173,8 +176,41 @@ __device__ __forceinline__ bool pathPixel(const FrameParams &fp, uint32_t q, int
     return x < fp.W && y < fp.H && (tile % fp.tileStride) == fp.tileOffset;
 }
 
+// Place of a pixel of an 8x8 tile along the Z curve (x in the even bits), and back: 4 consecutive places are a
+// 2x2 block, 16 a 4x4 block.
+__device__ __forceinline__ uint32_t tileCurve(uint32_t local) {   // local = y * 8 + x
+    const uint32_t x = local & 7u, y = local >> 3;
+    return (x & 1u) | ((y & 1u) << 1) | ((x & 2u) << 1) | ((y & 2u) << 2) | ((x & 4u) << 2) | ((y & 4u) << 3);
+}
+__device__ __forceinline__ uint32_t tileLocal(uint32_t curve) {
+    const uint32_t x = (curve & 1u) | ((curve >> 1) & 2u) | ((curve >> 2) & 4u), y = ((curve >> 1) & 1u) | ((curve >> 2) & 2u) | ((curve >> 3) & 4u);
+    return y * 8u + x;
+}
+// Tile-major order with B = waveSamples samples per wave: the K waves of a tile are K / B sample blocks of B pixel
+// groups; wave (block b, group g) holds samples b B .. b B + B - 1 of the 64 / B pixels at curve places g 64 / B ...
 __device__ __forceinline__ uint32_t pathIndex(const FrameParams &fp, const Batch &bt, uint32_t k, uint32_t q) {
-    return bt.planesInner ? ((((q >> 6) * bt.K + k) << 6) | (q & 63u)) : k * fp.npt + q;
+    if (!bt.planesInner) return k * fp.npt + q;
+    if (bt.waveSamples <= 1u) return (((q >> 6) * bt.K + k) << 6) | (q & 63u);
+    const uint32_t B = bt.waveSamples, per = 64u / B, place = tileCurve(q & 63u);
+    const uint32_t wave = (k / B) * B + place / per, lane = (k % B) * per + place % per;
+    return (((q >> 6) * bt.K + wave) << 6) | lane;
+}
+// The inverse: sample plane and padded pixel of path p.
+__device__ __forceinline__ void pathOf(const FrameParams &fp, const Batch &bt, uint32_t p, uint32_t &k, uint32_t &q) {
+    if (!bt.planesInner) {
+        k = p / fp.npt;
+        q = p - k * fp.npt;
+        return;
+    }
+    const uint32_t w = p >> 6, tile = w / bt.K, wave = w % bt.K, lane = p & 63u;
+    if (bt.waveSamples <= 1u) {
+        k = wave;
+        q = (tile << 6) | lane;
+        return;
+    }
+    const uint32_t B = bt.waveSamples, per = 64u / B;
+    k = (wave / B) * B + lane / per;
+    q = (tile << 6) | tileLocal((wave % B) * per + lane % per);
 }
 
 }  // namespace
