@@ -983,7 +983,9 @@ static int renderPlanes(rt_ctx *ctx, int pipeNo, uint64_t g0, uint64_t g1, uint3
         bt.frameStride = frame_stride;
         bt.P = ctx->P;
         bt.planesInner = ctx->planesInner ? 1u : 0u;
-        bt.waveSamples = (ctx->waveSamples > 1 && bt.K % (uint32_t)ctx->waveSamples == 0u) ? (uint32_t)ctx->waveSamples : 1u;
+        // (the largest power of two up to the setting that divides the batch's planes: 12 planes run with 4 per wave)
+        bt.waveSamples = (uint32_t)ctx->waveSamples;
+        while (bt.waveSamples > 1u && bt.K % bt.waveSamples != 0u) bt.waveSamples >>= 1;
         if ((rc = runBatch(ctx, bt)) != RT_OK) return rc;
     }
     if (e1) hipEventRecord(e1, ctx->stream);

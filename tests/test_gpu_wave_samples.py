@@ -1,7 +1,8 @@
-"""GPU: the order of the paths inside a batch when it holds a multiple of 16 sample planes.
+"""GPU: the order of the paths inside a batch of several sample planes.
 
-With 16 (or the RT_WAVE_SAMPLES value) planes or a multiple in a batch, a wave holds 16 samples of a 2x2-pixel block
-instead of one sample of 64 pixels (Batch::waveSamples, pathIndex / pathOf in csrc/rt_wavefront.h).  Which slot a
+A wave holds B samples of 64 / B pixels, B = the largest power of two up to 16 (or the RT_WAVE_SAMPLES value) that
+divides the batch's planes: 16 samples of a 2x2-pixel block for 16, 32, 48 ... planes, 4 samples of a 4x4 block for
+12, one sample of the 8x8 tile for an odd count (Batch::waveSamples, pathIndex / pathOf in csrc/rt_wavefront.h).  Which slot a
 (pixel, sample) pair occupies decides nothing about its value: seeds come from pixel, frame and sample
 (src/RayTracer.cpp:572), and the frame sum adds samples in sample order.  Bar: the checker's image bit for bit, for
 both integrators, hero wavelengths, ragged image sizes, tile-split shards and batches cut by the path ceiling.
@@ -32,8 +33,8 @@ def _setup(backend, name, kw, width, height, bounces, rpp, rtype):
     return scene, cam
 
 
-# (samples per frame, frames): 16, 16, 32, 64 and 48 planes in one batch; the last two of a plain count of 12 and 17
-CASES = [(4, 4), (16, 1), (4, 8), (16, 4), (16, 3), (4, 3), (1, 17)]
+# (samples per frame, frames): 16, 16, 32, 64 and 48 planes in one batch (16 per wave), 12 (4), 24 (8), 18 (2), 17 (1)
+CASES = [(4, 4), (16, 1), (4, 8), (16, 4), (16, 3), (4, 3), (4, 6), (9, 2), (1, 17)]
 
 
 @pytest.mark.parametrize("rtype", [capi.RT_TYPE_RGB, capi.RT_TYPE_SPECTRAL])
@@ -79,7 +80,7 @@ def test_unstratified_branch_with_blocks_of_samples(backend):
 
 def test_tile_shards_and_cut_batches_with_blocks_of_samples(backend):
     """32 planes: whole, as three tile-split shards, and with the path ceiling cutting the batch into pieces of 16,
-    of 5 and of 1 planes (the last two fall back to one sample per wave): the same image every time."""
+    of 5 (then 4 + 1 samples per wave) and of 1 planes: the same image every time."""
     W, H = 70, 45
     scene, cam = _setup(backend, "mixed", dict(nu=64, nv=12), W, H, 3, 4, capi.RT_TYPE_RGB)
     backend.reset_accum()
