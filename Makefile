@@ -86,6 +86,11 @@ sanitize: asan tsan
 	$(BUILD)/fuzz_host_asan glb 2000 4 $(BUILD)/fuzz_seeds/*.glb tests/golden/room.glb
 	$(BUILD)/fuzz_host_tsan selftest
 
+# Times validation, re-pack and the host tree builds on a scene written to files, without a device (tools/commit_host_time.cpp).
+$(BUILD)/commit_host_time: tools/commit_host_time.cpp $(CSRC)/rt_commit.cpp $(CSRC)/rt_commit.h $(CSRC)/rt_device.h
+	@mkdir -p $(BUILD)
+	$(CXX) $(COMMIT_FLAGS) tools/commit_host_time.cpp $(CSRC)/rt_commit.cpp -o $@
+
 # Microbenchmarks behind the roofline limits (tools/roofline_limits.sh runs the built binaries on the GPU box).
 MICRO := tools/microbench/gather64 tools/microbench/chain tools/microbench/fetch_calib tools/microbench/mix_calib
 microbench: $(MICRO)
