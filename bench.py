@@ -132,7 +132,10 @@ def main():
     distributed = world > 1
     if distributed:
         if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            try:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            except TypeError:   # (a torch without the argument: the communicator is made at the first collective)
+                dist.init_process_group("nccl")
         else:
             dist.init_process_group(args.dist_backend)
 
