@@ -127,7 +127,8 @@ int repackScene(rt_scene_host *ctx, PackedNodes &nodes, PackedTris &tris, Packed
             triangles += (uint64_t)std::max(f2i(info[(size_t)m * 4 + 0]), 0);
             treeNodes += (uint64_t)std::max(f2i(info[(size_t)m * 4 + 2]), 0);
         }
-        if (triangles >= (1u << 29) || treeNodes * kNodeWords > mdl.size()) return RT_ERR_SCENE;
+        // (every identifier and node the counts promise must be in the stream: the reservations below are sized by them)
+        if (triangles >= (1u << 29) || triangles * kIdentWords > mdl.size() || treeNodes * kNodeWords > mdl.size()) return RT_ERR_SCENE;
         tris.reserve((size_t)triangles);
         shade.reserve((size_t)triangles);
         uvs.reserve((size_t)triangles);
