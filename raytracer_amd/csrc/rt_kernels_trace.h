@@ -272,6 +272,18 @@ __global__ __launch_bounds__(kBlock, (COUNT && kCountingWaves > 0) ? kCountingWa
     const uint32_t waveId = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     int source = firstSource + (int)(waveId % (uint32_t)numSources);
     bool drained = false;    // every source has been seen empty
+    // Camera rays go out in whole 64-ray hands (refillLanes 64), all about as long: the hands of extension
+    // sub-queue s are dealt in turn to the waves numbered s, s + kSubQueues, ... instead of being taken from a
+    // cursor, which costs every hand an atomic's round trip before its rays can even be loaded (the stage's
+    // launch: 9.4 -> 6.6 ms on the default workload).  Neighbouring hands go to different waves, so every wave
+    // gets its share of the screen's cheap and dear parts.
+    const bool dealtHands = !ALPHA && !retraceList && refillLanes >= 64 && extParity >= 0;   // (the alpha-cut instances have no register to spare for it)
+    const uint32_t handStride = (gridDim.x * (kBlock / 64)) / (uint32_t)kSubQueues;   // waves per sub-queue that take part
+    uint32_t nextHand = waveId / (uint32_t)kSubQueues;
+    if (dealtHands) {
+        source = (int)(waveId % (uint32_t)kSubQueues);
+        if (nextHand >= handStride) drained = true;   // (the few waves beyond a whole number of rounds)
+    }
 
     uint32_t cntNodes = 0, cntTris = 0, maxSp = 0;
     // COUNT only, wave-uniform: loop steps that ran a phase, the active lanes summed over those steps,
@@ -436,9 +448,17 @@ __global__ __launch_bounds__(kBlock, (COUNT && kCountingWaves > 0) ? kCountingWa
             const uint32_t n = lengthOf(sq);
             const int leader = __ffsll((long long)idleMask) - 1;
             uint32_t base = n;
-            if (n != 0u) {
+            if (dealtHands) {
+                base = nextHand * 64u;
+                nextHand += handStride;
+                if (base >= n) drained = true;
+            } else if (n != 0u) {
                 if ((int)lane == leader) base = atomicAdd(&sq->cursor, (uint32_t)nIdle);
                 base = __shfl(base, leader);
+            }
+            if (dealtHands && base >= n) {
+                if (nIdle == 64) break;
+                continue;
             }
             if (base >= n) {
                 bool has = false;
